@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on its configuration:
+
+    Mrays/s (+ ms/frame), 512^3 LSVO terrain @ 1920x1080, 4 spp GI, N GPUs.
+
+A "step" is one frame: every pixel, `spp` accumulated renderRay-equivalents
+(primary + shadow + GI + GI-shadow rays, reference semantics: one indirect
+bounce = camera hit + GI hit, raycaster.hpp:169-207) through the persistent HIP
+frame kernel, the sample resolve, and -- for N > 1 -- the row-block shard pack,
+the RCCL all-gather of the RGBA8 framebuffer and the unpack.  rays = traversals
+actually executed (counted by the kernel, equal to the oracle's count).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: depth, width, height, spp, use_gi, aperture
+    "c2": dict(depth=8, width=1280, height=720, spp=1, use_gi=0, aperture=0.0,
+               label="256^3 LSVO terrain, 1280x720, primary + 1 shadow ray"),
+    "c3": dict(depth=9, width=1920, height=1080, spp=4, use_gi=1, aperture=0.0,
+               label="512^3 LSVO terrain (FastNoise fixture), 1920x1080, 4 spp GI (1 indirect bounce), shadow_samples=1"),
+    "c4": dict(depth=9, width=1920, height=1080, spp=4, use_gi=1, aperture=0.5,
+               label="512^3 LSVO terrain, 1920x1080, 4 spp GI + DOF (aperture 0.5)"),
+    "c5": dict(depth=10, width=3840, height=2160, spp=16, use_gi=1, aperture=0.0,
+               label="1024^3 LSVO terrain, 3840x2160, 16 spp GI"),
+}
+ROW_BLOCK = 8
+HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(cfg, nodes, textures, cam, light, budget_s=12.0):
+    """The oracle (bit-identical CPU restatement, kind "port") timed on this box's
+    host cores on a bounded sample of the same workload: 1/16-frame row-block
+    shards of the same frame, one sample each, until ~budget_s seconds."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    threads = max(1, min(os.cpu_count() or 1, 64))
+    top, side = textures
+    ocam = O.make_camera(tuple(cam.position), tuple(cam.rot), cam.fov, cam.aperture, cam.focal_length)
+    W, H = cfg["width"], cfg["height"]
+    rays = 0
+    done = 0
+    t0 = time.perf_counter()
+    shards = 16
+    for s in range(cfg["spp"]):
+        for k in range(shards):
+            p = O.make_params(W, H, light, use_gi=cfg["use_gi"], use_samples=1, shadow_samples=1, frame_index=s,
+                              row_block=ROW_BLOCK, shard_index=k, shard_count=shards)
+            _, _, _, st = O.render_frame(nodes, cfg["depth"], top, side, ocam, p, threads=threads)
+            rays += st.rays
+            done += 1
+            if time.perf_counter() - t0 > budget_s:
+                break
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"{done} of {shards * cfg['spp']} 1/{shards}-frame row-block shards (1 sample each) of the same "
+                      f"workload, {rays} rays in {dt:.1f} s, oracle built -O2 -ffp-contract=off, OpenMP {threads} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--pitch", type=float, default=-0.5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tuning", default="", help="blocks_per_cu,refill_threshold,chunk")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import __graft_entry__ as g
+    import cpuvoxelraycaster_amd as vrc
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if not os.path.exists(vrc.capi.LIB_PATH):
+        g.build()
+    if args.tuning:
+        vrc.capi.check(vrc.capi.load().vrc_set_tuning(*[int(v) for v in args.tuning.split(",")]))
+
+    cfg = CONFIGS[args.config]
+    depth, W, H, spp = cfg["depth"], cfg["width"], cfg["height"], cfg["spp"]
+    heights = vrc.load_terrain_heights()
+    textures = vrc.load_textures()
+    nodes = vrc.build_terrain_lsvo(heights, depth)           # product host builder (csrc/vrc_builder.cpp)
+    svo = vrc.LSVO(nodes, depth, device=local_rank, textures=textures)   # LNode[] resident in HBM from here on
+    rc = vrc.RayCaster(svo, (W, H))
+    light = vrc.reference_light(depth)
+    rc.setLightPosition(light)
+    rc.use_gi, rc.use_samples, rc.shadow_samples = bool(cfg["use_gi"]), True, 1
+    cam = vrc.reference_camera(depth, pitch=args.pitch, aperture=cfg["aperture"],
+                               focal_length=(60.0 * (1 << depth) / 512.0 if cfg["aperture"] else 1.0))
+    stream = torch.cuda.current_stream().cuda_stream
+    L = vrc.capi.load()
+
+    shard_bytes = L.vrc_shard_bytes(W, H, ROW_BLOCK, world)
+    if world > 1:
+        mine = torch.empty(shard_bytes, dtype=torch.uint8, device="cuda")
+        gathered = torch.empty(world * shard_bytes, dtype=torch.uint8, device="cuda")
+        full = torch.empty(H * W * 4, dtype=torch.uint8, device="cuda")
+
+    ev_pairs = []
+
+    def step(timed):
+        rc.resetSamples(stream)
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        if world > 1:
+            rc.renderFrame(cam, spp=spp, stream=stream, row_block=ROW_BLOCK, shard_index=rank, shard_count=world)
+        else:
+            rc.renderFrame(cam, spp=spp, stream=stream)
+        e1.record()
+        rc.samples_to_image(stream)
+        if world > 1:
+            rc.packShard(ROW_BLOCK, rank, world, mine.data_ptr(), stream)
+            dist.all_gather_into_tensor(gathered, mine)       # RCCL over xGMI: RGBA8 row-block shards
+            vrc.capi.check(L.vrc_unpack_shards(vrc.capi.ptr(gathered.data_ptr()), W, H, ROW_BLOCK, world,
+                                               vrc.capi.ptr(full.data_ptr()), vrc.capi.ptr(stream)))
+        if timed:
+            ev_pairs.append((e0, e1))
+
+    for _ in range(args.warmup):
+        step(False)
+    rc.stats(reset=True, stream=stream)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    st = rc.stats(stream=stream)
+    kernel_ms = sum(a.elapsed_time(b) for a, b in ev_pairs) / max(1, len(ev_pairs))
+
+    rays, steps_sum, pixels = st.rays, st.sum_complexity, st.pixels
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        c = torch.tensor([rays, steps_sum, pixels], dtype=torch.int64, device="cuda")
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        rays, steps_sum, pixels = (int(v) for v in c.tolist())
+        km = torch.tensor([kernel_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(km, op=dist.ReduceOp.MAX)
+        kernel_ms_max = float(km.item())
+    else:
+        kernel_ms_max = kernel_ms
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        # roofline of the dominant kernel (k_render), this rank's launches:
+        # algorithmic bytes per launch = 8 B per traversal-loop iteration (one LNode, lsvo.hpp:74)
+        # + one 32 B accumulator read-modify-write per pixel of the launch (raycaster.hpp:87-90)
+        my_steps_per_launch = st.sum_complexity / args.steps
+        my_pixels_per_launch = st.pixels / args.steps / spp
+        alg_bytes = 8.0 * my_steps_per_launch + 32.0 * my_pixels_per_launch
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        prof = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(prof):
+            try:
+                traffic = json.load(open(prof)).get(f"{args.config}_n{world}")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mrays/s + ms/frame, 512^3 LSVO @1920x1080 4spp GI, 1/2/4/8 GPU",
+            "value": round(rays / elapsed / 1e6, 2),
+            "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": cfg["label"], "rays_per_frame": rays // args.steps,
+                       "loop_iterations_per_frame": steps_sum // args.steps,
+                       "camera_pitch": args.pitch, "sharding": f"{ROW_BLOCK}-row blocks round-robin over {world} GPU(s)"
+                       + (", RCCL all-gather of RGBA8 shards" if world > 1 else "")},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
+                         "kernel": "k_render", "kernel_ms": round(kernel_ms, 4), "kernel_ms_max_rank": round(kernel_ms_max, 4),
+                         "algorithmic_bytes_per_launch": int(alg_bytes)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, nodes, textures, cam, light)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

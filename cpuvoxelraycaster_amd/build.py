@@ -1,0 +1,39 @@
+"""Builds libvrc_hip.so (HIP kernels + C ABI) in-tree for gfx950 with hipcc."""
+import os
+import subprocess
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+LIB = os.path.join(PKG, "libvrc_hip.so")
+SOURCES = ["vrc_kernels.hip", "vrc_api.cpp", "vrc_builder.cpp"]
+HEADERS = ["vrc_device.h", "vrc_internal.h", os.path.join("..", "..", "include", "vrc.h")]
+
+# -ffp-contract=off: hipcc fuses a*b+c into v_fma_f32 by default, which changes
+# which voxel a ray hits.  Correctly rounded f32 divide and
+# sqrt are hipcc's default; stated explicitly because parity depends on them.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+         "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt",
+         "-fno-fast-math", "-Wall", "-Wno-unused-result"]
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_native(force=False, verbose=False):
+    if not force and not needs_build():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + FLAGS + ["-x", "hip"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_native(force=True, verbose=True))

@@ -1,0 +1,515 @@
+// vrc_api.cpp -- the C ABI declared in include/vrc.h (device memory, streams,
+// launches).  Compiled with hipcc into libvrc_hip.so together with
+// vrc_kernels.hip and vrc_builder.cpp.  No CPU compute fallback: every entry
+// point that casts rays needs a HIP device and fails loudly without one.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "../../include/vrc.h"
+#include "vrc_internal.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) return fail(VRC_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+struct Tuning {
+    uint32_t blocks_per_cu = 8;
+    uint32_t refill_threshold = 16;
+    uint32_t chunk = 512;
+} g_tuning;
+
+}  // namespace
+
+struct vrc_scene {
+    int device;
+    int cu_count;
+    void* d_nodes;
+    void* d_tex;  // 1536 bytes
+    uint64_t n_nodes;
+    uint32_t depth;
+};
+
+struct vrc_grid {
+    int device;
+    void* d_cells;
+    int32_t X, Y, Z;
+};
+
+struct vrc_renderer {
+    const vrc_scene* scene;
+    uint32_t width, height;
+    void* d_image;  // RGBA8
+    void* d_accum;  // 4 x u32 per pixel
+    void* d_stats;  // 4 x u64 + queue head (u32) at byte 32
+    vrc_hit* d_prim;
+};
+
+extern "C" const char* vrc_last_error(void) { return g_err; }
+
+extern "C" int vrc_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fail(VRC_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    return n;
+}
+
+static int require_device(int device, int* cu_count)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(VRC_ERR_NO_DEVICE, "no HIP device available (%s); this library has no CPU fallback",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    if (device < 0 || device >= n) return fail(VRC_ERR_INVALID, "device %d out of range [0,%d)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    if (cu_count) {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device));
+        *cu_count = prop.multiProcessorCount;
+    }
+    return VRC_OK;
+}
+
+extern "C" int vrc_set_tuning(uint32_t blocks_per_cu, uint32_t refill_threshold, uint32_t chunk)
+{
+    if (blocks_per_cu > 8 || refill_threshold > 64) return fail(VRC_ERR_INVALID, "tuning out of range");
+    g_tuning.blocks_per_cu = blocks_per_cu ? blocks_per_cu : 8;
+    g_tuning.refill_threshold = refill_threshold ? refill_threshold : 16;
+    g_tuning.chunk = chunk ? ((chunk + 63u) & ~63u) : 512;
+    return VRC_OK;
+}
+
+// ---------------------------------------------------------------------------
+// scene
+// ---------------------------------------------------------------------------
+
+extern "C" int vrc_scene_create(const vrc_lnode* lnodes, uint64_t n_nodes, uint32_t depth, int device, vrc_scene** out)
+{
+    if (!lnodes || !out || n_nodes == 0) return fail(VRC_ERR_INVALID, "vrc_scene_create: null / empty input");
+    if (depth < 2 || depth > VRC_MAX_DEPTH) return fail(VRC_ERR_INVALID, "vrc_scene_create: depth %u not in [2,%d]", depth, VRC_MAX_DEPTH);
+    if (n_nodes > 0xffffffffull) return fail(VRC_ERR_INVALID, "vrc_scene_create: node indices are 32-bit");
+    int cus = 0;
+    int rc = require_device(device, &cus);
+    if (rc) return rc;
+    vrc_scene* s = (vrc_scene*)calloc(1, sizeof(vrc_scene));
+    if (!s) return fail(VRC_ERR_OOM, "out of host memory");
+    s->device = device; s->cu_count = cus; s->n_nodes = n_nodes; s->depth = depth;
+    hipError_t e = hipMalloc(&s->d_nodes, n_nodes * sizeof(vrc_lnode));
+    if (e == hipSuccess) e = hipMalloc(&s->d_tex, 1536);
+    if (e == hipSuccess) e = hipMemcpy(s->d_nodes, lnodes, n_nodes * sizeof(vrc_lnode), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(s->d_tex, 0xff, 1536);  // sf::Color::White until textures are set
+    if (e != hipSuccess) {
+        if (s->d_nodes) (void)hipFree(s->d_nodes);
+        if (s->d_tex) (void)hipFree(s->d_tex);
+        free(s);
+        return fail(e == hipErrorOutOfMemory ? VRC_ERR_OOM : VRC_ERR_HIP, "vrc_scene_create: %s", hipGetErrorString(e));
+    }
+    *out = s;
+    return VRC_OK;
+}
+
+extern "C" int vrc_scene_set_textures(vrc_scene* s, const uint8_t top_rgb[768], const uint8_t side_rgb[768])
+{
+    if (!s || !top_rgb || !side_rgb) return fail(VRC_ERR_INVALID, "vrc_scene_set_textures: null argument");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipMemcpy(s->d_tex, top_rgb, 768, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy((uint8_t*)s->d_tex + 768, side_rgb, 768, hipMemcpyHostToDevice));
+    return VRC_OK;
+}
+
+extern "C" int vrc_scene_destroy(vrc_scene* s)
+{
+    if (!s) return VRC_OK;
+    (void)hipSetDevice(s->device);
+    (void)hipFree(s->d_nodes);
+    (void)hipFree(s->d_tex);
+    free(s);
+    return VRC_OK;
+}
+
+extern "C" uint64_t vrc_scene_node_count(const vrc_scene* s) { return s ? s->n_nodes : 0; }
+extern "C" uint32_t vrc_scene_depth(const vrc_scene* s) { return s ? s->depth : 0; }
+
+// ---------------------------------------------------------------------------
+// per-ray operator
+// ---------------------------------------------------------------------------
+
+namespace {
+
+// Stage host ray buffers through device memory around `launch`.
+template <class Launch>
+int staged_cast(uint64_t n, const float* org, const float* dir, const float* coef, const float* bias, vrc_hit* out,
+                hipStream_t st, Launch launch)
+{
+    float *d_org = nullptr, *d_dir = nullptr, *d_coef = nullptr, *d_bias = nullptr;
+    vrc_hit* d_out = nullptr;
+    hipError_t e = hipMalloc((void**)&d_org, n * 12);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_dir, n * 12);
+    if (e == hipSuccess && coef) e = hipMalloc((void**)&d_coef, n * 4);
+    if (e == hipSuccess && bias) e = hipMalloc((void**)&d_bias, n * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_out, n * sizeof(vrc_hit));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_org, org, n * 12, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_dir, dir, n * 12, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && coef) e = hipMemcpyAsync(d_coef, coef, n * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && bias) e = hipMemcpyAsync(d_bias, bias, n * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = launch(d_org, d_dir, d_coef, d_bias, d_out);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, n * sizeof(vrc_hit), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(d_org); (void)hipFree(d_dir); (void)hipFree(d_coef); (void)hipFree(d_bias); (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? VRC_ERR_OOM : VRC_ERR_HIP, "cast_rays: %s", hipGetErrorString(e));
+    return VRC_OK;
+}
+
+}  // namespace
+
+extern "C" int vrc_cast_rays(const vrc_scene* s, uint64_t n, const float* org_xyz, const float* dir_xyz, const float* coef,
+                             const float* bias, vrc_hit* out, int mem, void* stream)
+{
+    if (!s) return fail(VRC_ERR_INVALID, "vrc_cast_rays: null scene");
+    if (n == 0) return VRC_OK;
+    if (!org_xyz || !dir_xyz || !out) return fail(VRC_ERR_INVALID, "vrc_cast_rays: null buffer");
+    if (n > 0xffffffffull * 256ull) return fail(VRC_ERR_INVALID, "vrc_cast_rays: too many rays for one launch");
+    HIP_TRY(hipSetDevice(s->device));
+    hipStream_t st = (hipStream_t)stream;
+    if (mem == VRC_MEM_DEVICE) {
+        HIP_TRY(vrc::launch_cast_rays(s->d_nodes, (int)s->depth, n, org_xyz, dir_xyz, coef, bias, out, st));
+        return VRC_OK;
+    }
+    if (mem != VRC_MEM_HOST) return fail(VRC_ERR_INVALID, "vrc_cast_rays: bad mem kind %d", mem);
+    return staged_cast(n, org_xyz, dir_xyz, coef, bias, out, st,
+                       [&](float* o, float* d, float* c, float* b, vrc_hit* h) {
+                           return vrc::launch_cast_rays(s->d_nodes, (int)s->depth, n, o, d, c, b, h, st);
+                       });
+}
+
+extern "C" int vrc_cast_ray(const vrc_scene* s, const float org[3], const float dir[3], float ray_size_coef,
+                            float ray_size_bias, vrc_hit* out)
+{
+    return vrc_cast_rays(s, 1, org, dir, &ray_size_coef, &ray_size_bias, out, VRC_MEM_HOST, nullptr);
+}
+
+// ---------------------------------------------------------------------------
+// dense grid
+// ---------------------------------------------------------------------------
+
+extern "C" int vrc_grid_create(const uint8_t* cells, int32_t X, int32_t Y, int32_t Z, int device, vrc_grid** out)
+{
+    if (!cells || !out || X <= 0 || Y <= 0 || Z <= 0) return fail(VRC_ERR_INVALID, "vrc_grid_create: bad argument");
+    int rc = require_device(device, nullptr);
+    if (rc) return rc;
+    vrc_grid* g = (vrc_grid*)calloc(1, sizeof(vrc_grid));
+    if (!g) return fail(VRC_ERR_OOM, "out of host memory");
+    g->device = device; g->X = X; g->Y = Y; g->Z = Z;
+    const size_t bytes = (size_t)X * Y * Z;
+    hipError_t e = hipMalloc(&g->d_cells, bytes);
+    if (e == hipSuccess) e = hipMemcpy(g->d_cells, cells, bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (g->d_cells) (void)hipFree(g->d_cells);
+        free(g);
+        return fail(e == hipErrorOutOfMemory ? VRC_ERR_OOM : VRC_ERR_HIP, "vrc_grid_create: %s", hipGetErrorString(e));
+    }
+    *out = g;
+    return VRC_OK;
+}
+
+extern "C" int vrc_grid_destroy(vrc_grid* g)
+{
+    if (!g) return VRC_OK;
+    (void)hipSetDevice(g->device);
+    (void)hipFree(g->d_cells);
+    free(g);
+    return VRC_OK;
+}
+
+extern "C" int vrc_grid_cast_rays(const vrc_grid* g, uint64_t n, const float* org_xyz, const float* dir_xyz, vrc_hit* out,
+                                  int mem, void* stream)
+{
+    if (!g) return fail(VRC_ERR_INVALID, "vrc_grid_cast_rays: null grid");
+    if (n == 0) return VRC_OK;
+    if (!org_xyz || !dir_xyz || !out) return fail(VRC_ERR_INVALID, "vrc_grid_cast_rays: null buffer");
+    HIP_TRY(hipSetDevice(g->device));
+    hipStream_t st = (hipStream_t)stream;
+    if (mem == VRC_MEM_DEVICE) {
+        HIP_TRY(vrc::launch_grid_cast((const uint8_t*)g->d_cells, g->X, g->Y, g->Z, n, org_xyz, dir_xyz, out, st));
+        return VRC_OK;
+    }
+    if (mem != VRC_MEM_HOST) return fail(VRC_ERR_INVALID, "vrc_grid_cast_rays: bad mem kind %d", mem);
+    return staged_cast(n, org_xyz, dir_xyz, nullptr, nullptr, out, st,
+                       [&](float* o, float* d, float*, float*, vrc_hit* h) {
+                           return vrc::launch_grid_cast((const uint8_t*)g->d_cells, g->X, g->Y, g->Z, n, o, d, h, st);
+                       });
+}
+
+// ---------------------------------------------------------------------------
+// renderer
+// ---------------------------------------------------------------------------
+
+extern "C" int vrc_renderer_create(const vrc_scene* s, uint32_t width, uint32_t height, vrc_renderer** out)
+{
+    if (!s || !out || width == 0 || height == 0) return fail(VRC_ERR_INVALID, "vrc_renderer_create: bad argument");
+    if ((uint64_t)width * height > 0x7fffffffull) return fail(VRC_ERR_INVALID, "vrc_renderer_create: frame too large");
+    HIP_TRY(hipSetDevice(s->device));
+    vrc_renderer* r = (vrc_renderer*)calloc(1, sizeof(vrc_renderer));
+    if (!r) return fail(VRC_ERR_OOM, "out of host memory");
+    r->scene = s; r->width = width; r->height = height;
+    const uint64_t n = (uint64_t)width * height;
+    hipError_t e = hipMalloc(&r->d_image, n * 4);
+    if (e == hipSuccess) e = hipMalloc(&r->d_accum, n * 16);
+    if (e == hipSuccess) e = hipMalloc(&r->d_stats, 64);
+    if (e == hipSuccess) e = hipMemset(r->d_accum, 0, n * 16);
+    if (e == hipSuccess) e = hipMemset(r->d_stats, 0, 64);
+    if (e == hipSuccess) e = vrc::launch_fill_u32(r->d_image, 0xff000000u, n, nullptr);  // sf::Image::create: opaque black
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+        if (r->d_image) (void)hipFree(r->d_image);
+        if (r->d_accum) (void)hipFree(r->d_accum);
+        if (r->d_stats) (void)hipFree(r->d_stats);
+        free(r);
+        return fail(e == hipErrorOutOfMemory ? VRC_ERR_OOM : VRC_ERR_HIP, "vrc_renderer_create: %s", hipGetErrorString(e));
+    }
+    *out = r;
+    return VRC_OK;
+}
+
+extern "C" int vrc_renderer_destroy(vrc_renderer* r)
+{
+    if (!r) return VRC_OK;
+    (void)hipSetDevice(r->scene->device);
+    (void)hipFree(r->d_image);
+    (void)hipFree(r->d_accum);
+    (void)hipFree(r->d_stats);
+    free(r);
+    return VRC_OK;
+}
+
+extern "C" int vrc_renderer_set_primary_capture(vrc_renderer* r, vrc_hit* prim_dev)
+{
+    if (!r) return fail(VRC_ERR_INVALID, "null renderer");
+    r->d_prim = prim_dev;
+    return VRC_OK;
+}
+
+extern "C" int vrc_render_frame(vrc_renderer* r, const vrc_camera* cam, const vrc_frame_params* p, void* stream)
+{
+    if (!r || !cam || !p) return fail(VRC_ERR_INVALID, "vrc_render_frame: null argument");
+    if (p->gi_bounces > 2) return fail(VRC_ERR_INVALID, "vrc_render_frame: gi_bounces %u > 2 not supported", p->gi_bounces);
+    if (p->checker_parity < -1 || p->checker_parity > 1) return fail(VRC_ERR_INVALID, "vrc_render_frame: checker_parity must be -1, 0 or 1");
+    if (p->row_block && p->shard_count > 1) {
+        if (p->row_block % 8u) return fail(VRC_ERR_INVALID, "vrc_render_frame: row_block must be a multiple of 8");
+        if (p->shard_index >= p->shard_count) return fail(VRC_ERR_INVALID, "vrc_render_frame: shard_index >= shard_count");
+    }
+    const vrc_scene* s = r->scene;
+    HIP_TRY(hipSetDevice(s->device));
+    hipStream_t st = (hipStream_t)stream;
+    vrc::FrameArgs a;
+    memset(&a, 0, sizeof(a));
+    a.nodes = (const uint2*)s->d_nodes;
+    a.tex = (const uint8_t*)s->d_tex;
+    a.image = (uint8_t*)r->d_image;
+    a.accum = (uint32_t*)r->d_accum;
+    a.prim = r->d_prim;
+    a.stats = (uint64_t*)r->d_stats;
+    a.queue = (uint32_t*)((uint8_t*)r->d_stats + 32);
+    a.depth = s->depth; a.width = r->width; a.height = r->height;
+    a.cam = *cam;
+    a.p = *p;
+    if (a.p.spp == 0) a.p.spp = 1;
+    // rows this shard owns, in compact row space
+    uint32_t rows = r->height;
+    if (p->row_block && p->shard_count > 1) {
+        const uint32_t nblocks = (r->height + p->row_block - 1) / p->row_block;
+        const uint32_t mine = nblocks > p->shard_index ? (nblocks - p->shard_index + p->shard_count - 1) / p->shard_count : 0;
+        rows = mine * p->row_block;
+    } else {
+        a.p.row_block = 0; a.p.shard_index = 0; a.p.shard_count = 1;
+    }
+    const uint32_t tiles_per_row = (r->width + 7u) / 8u;
+    const uint64_t items = (uint64_t)tiles_per_row * ((rows + 7u) / 8u) * 64ull;
+    if (items > 0xfffffff0ull) return fail(VRC_ERR_INVALID, "vrc_render_frame: frame too large");
+    a.n_items = (uint32_t)items;
+    a.chunk = g_tuning.chunk;
+    a.refill_threshold = g_tuning.refill_threshold;
+    if (a.n_items == 0) return VRC_OK;
+    HIP_TRY(hipMemsetAsync(a.queue, 0, 4, st));
+    uint64_t want = (items + VRC_RENDER_BLOCK - 1) / VRC_RENDER_BLOCK;
+    const uint64_t cap = (uint64_t)s->cu_count * g_tuning.blocks_per_cu;
+    const uint32_t grid = (uint32_t)(want < cap ? want : cap);
+    HIP_TRY(vrc::launch_render(a, grid, st));
+    return VRC_OK;
+}
+
+extern "C" int vrc_samples_to_image(vrc_renderer* r, void* stream)
+{
+    if (!r) return fail(VRC_ERR_INVALID, "null renderer");
+    HIP_TRY(hipSetDevice(r->scene->device));
+    HIP_TRY(vrc::launch_resolve(r->d_accum, r->d_image, r->width * r->height, (hipStream_t)stream));
+    return VRC_OK;
+}
+
+extern "C" int vrc_reset_samples(vrc_renderer* r, void* stream)
+{
+    if (!r) return fail(VRC_ERR_INVALID, "null renderer");
+    HIP_TRY(hipSetDevice(r->scene->device));
+    HIP_TRY(hipMemsetAsync(r->d_accum, 0, (uint64_t)r->width * r->height * 16, (hipStream_t)stream));
+    return VRC_OK;
+}
+
+extern "C" int vrc_clear_image(vrc_renderer* r, void* stream)
+{
+    if (!r) return fail(VRC_ERR_INVALID, "null renderer");
+    HIP_TRY(hipSetDevice(r->scene->device));
+    HIP_TRY(vrc::launch_fill_u32(r->d_image, 0xff000000u, (uint64_t)r->width * r->height, (hipStream_t)stream));
+    return VRC_OK;
+}
+
+extern "C" void* vrc_image_device_ptr(vrc_renderer* r) { return r ? r->d_image : nullptr; }
+extern "C" void* vrc_accum_device_ptr(vrc_renderer* r) { return r ? r->d_accum : nullptr; }
+
+extern "C" int vrc_read_image(vrc_renderer* r, uint8_t* rgba_host, void* stream)
+{
+    if (!r || !rgba_host) return fail(VRC_ERR_INVALID, "vrc_read_image: null argument");
+    HIP_TRY(hipSetDevice(r->scene->device));
+    HIP_TRY(hipMemcpyAsync(rgba_host, r->d_image, (uint64_t)r->width * r->height * 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return VRC_OK;
+}
+
+extern "C" int vrc_write_image(vrc_renderer* r, const uint8_t* rgba_host, void* stream)
+{
+    if (!r || !rgba_host) return fail(VRC_ERR_INVALID, "vrc_write_image: null argument");
+    HIP_TRY(hipSetDevice(r->scene->device));
+    HIP_TRY(hipMemcpyAsync(r->d_image, rgba_host, (uint64_t)r->width * r->height * 4, hipMemcpyHostToDevice, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return VRC_OK;
+}
+
+extern "C" int vrc_read_accum(vrc_renderer* r, uint32_t* accum_host, void* stream)
+{
+    if (!r || !accum_host) return fail(VRC_ERR_INVALID, "vrc_read_accum: null argument");
+    HIP_TRY(hipSetDevice(r->scene->device));
+    HIP_TRY(hipMemcpyAsync(accum_host, r->d_accum, (uint64_t)r->width * r->height * 16, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return VRC_OK;
+}
+
+extern "C" int vrc_get_stats(vrc_renderer* r, vrc_frame_stats* out, int reset, void* stream)
+{
+    if (!r || !out) return fail(VRC_ERR_INVALID, "vrc_get_stats: null argument");
+    HIP_TRY(hipSetDevice(r->scene->device));
+    uint64_t h[4];
+    HIP_TRY(hipMemcpyAsync(h, r->d_stats, 32, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    out->rays = h[0]; out->sum_complexity = h[1]; out->primary_hits = h[2]; out->pixels = h[3];
+    if (reset) {
+        HIP_TRY(hipMemsetAsync(r->d_stats, 0, 32, (hipStream_t)stream));
+        HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    }
+    return VRC_OK;
+}
+
+// ---------------------------------------------------------------------------
+// multi-GPU shard plumbing
+// ---------------------------------------------------------------------------
+
+static uint32_t shard_slots(uint32_t height, uint32_t row_block, uint32_t shard_count)
+{
+    const uint32_t nblocks = (height + row_block - 1) / row_block;
+    return (nblocks + shard_count - 1) / shard_count;
+}
+
+extern "C" uint64_t vrc_shard_bytes(uint32_t width, uint32_t height, uint32_t row_block, uint32_t shard_count)
+{
+    if (!row_block || !shard_count) return 0;
+    return (uint64_t)shard_slots(height, row_block, shard_count) * row_block * width * 4ull;
+}
+
+extern "C" int vrc_pack_shard(vrc_renderer* r, uint32_t row_block, uint32_t shard_index, uint32_t shard_count, void* dst_dev,
+                              void* stream)
+{
+    if (!r || !dst_dev || !row_block || !shard_count || shard_index >= shard_count)
+        return fail(VRC_ERR_INVALID, "vrc_pack_shard: bad argument");
+    HIP_TRY(hipSetDevice(r->scene->device));
+    HIP_TRY(vrc::launch_pack_shard(r->d_image, r->width, r->height, row_block, shard_index, shard_count,
+                                   shard_slots(r->height, row_block, shard_count), dst_dev, (hipStream_t)stream));
+    return VRC_OK;
+}
+
+extern "C" int vrc_unpack_shards(const void* gathered_dev, uint32_t width, uint32_t height, uint32_t row_block,
+                                 uint32_t shard_count, void* image_dev, void* stream)
+{
+    if (!gathered_dev || !image_dev || !row_block || !shard_count || !width || !height)
+        return fail(VRC_ERR_INVALID, "vrc_unpack_shards: bad argument");
+    HIP_TRY(vrc::launch_unpack_shards(gathered_dev, width, height, row_block, shard_count,
+                                      shard_slots(height, row_block, shard_count), image_dev, (hipStream_t)stream));
+    return VRC_OK;
+}
+
+// ---------------------------------------------------------------------------
+// host helper: generateRotationMatrix (utils.cpp:94-100) = mat3(ry * rx) with
+// rx = rotate(I, -angle.x, Y), ry = rotate(I, -angle.y, X); glm::rotate is the
+// axis-angle form.  Columns m[0], m[1], m[2].
+// ---------------------------------------------------------------------------
+
+namespace {
+struct M4 { float c[4][4]; };
+M4 m4_identity()
+{
+    M4 m;
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) m.c[i][j] = (i == j) ? 1.0f : 0.0f;
+    return m;
+}
+M4 m4_rotate(const M4& m, float angle, float ax, float ay, float az)
+{
+    const float c = std::cos(angle), s = std::sin(angle);
+    const float inv = 1.0f / std::sqrt((ax * ax + ay * ay) + az * az);
+    ax *= inv; ay *= inv; az *= inv;
+    const float tx = (1.0f - c) * ax, ty = (1.0f - c) * ay, tz = (1.0f - c) * az;
+    float R[3][3];
+    R[0][0] = c + tx * ax;      R[0][1] = tx * ay + s * az; R[0][2] = tx * az - s * ay;
+    R[1][0] = ty * ax - s * az; R[1][1] = c + ty * ay;      R[1][2] = ty * az + s * ax;
+    R[2][0] = tz * ax + s * ay; R[2][1] = tz * ay - s * ax; R[2][2] = c + tz * az;
+    M4 out;
+    for (int i = 0; i < 3; ++i)
+        for (int r = 0; r < 4; ++r) out.c[i][r] = (m.c[0][r] * R[i][0] + m.c[1][r] * R[i][1]) + m.c[2][r] * R[i][2];
+    for (int r = 0; r < 4; ++r) out.c[3][r] = m.c[3][r];
+    return out;
+}
+M4 m4_mul(const M4& A, const M4& B)
+{
+    M4 out;
+    for (int j = 0; j < 4; ++j)
+        for (int r = 0; r < 4; ++r)
+            out.c[j][r] = ((A.c[0][r] * B.c[j][0] + A.c[1][r] * B.c[j][1]) + A.c[2][r] * B.c[j][2]) + A.c[3][r] * B.c[j][3];
+    return out;
+}
+}  // namespace
+
+extern "C" void vrc_make_rotation(float angle_x, float angle_y, float rot[9])
+{
+    const M4 rx = m4_rotate(m4_identity(), -angle_x, 0.0f, 1.0f, 0.0f);
+    const M4 ry = m4_rotate(m4_identity(), -angle_y, 1.0f, 0.0f, 0.0f);
+    const M4 m = m4_mul(ry, rx);
+    for (int j = 0; j < 3; ++j)
+        for (int r = 0; r < 3; ++r) rot[j * 3 + r] = m.c[j][r];
+}

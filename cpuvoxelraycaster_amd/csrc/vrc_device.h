@@ -1,0 +1,239 @@
+// vrc_device.h -- device-side restatement of the reference's per-ray arithmetic
+// for gfx950 (wave64).  Included by vrc_kernels.hip only.
+//
+// Bit-exactness contract: the octree walk is
+// driven by float comparisons, so every operation below is written in the
+// reference's order and the file is compiled with -ffp-contract=off (hipcc
+// fuses a*b+c into v_fma_f32 by default, which changes hit voxels) and with
+// correctly rounded f32 divide / sqrt.  std::max / std::min are restated as
+// the exact ternaries (argument order matters for NaN and signed zeros).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vrc {
+
+__device__ __forceinline__ float smax(float a, float b) { return (a < b) ? b : a; }  // std::max(a,b)
+__device__ __forceinline__ float smin(float a, float b) { return (b < a) ? b : a; }  // std::min(a,b)
+__device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }       // utils.cpp:109-112
+__device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }       // utils.cpp:115-118
+// utils.cpp:60-64 std::modf fractional part: f - trunc(f) is exact; copysign keeps modf's -0.
+__device__ __forceinline__ float fracf_(float f) { return copysignf(f - truncf(f), f); }
+// glm::dot / glm::normalize (stock scalar GLM)
+__device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz)
+{
+    return (ax * bx + ay * by) + az * bz;
+}
+__device__ __forceinline__ void normalize3(float& x, float& y, float& z)
+{
+    const float inv = 1.0f / sqrtf(dot3(x, y, z, x, y, z));
+    x = x * inv; y = y * inv; z = z * inv;
+}
+
+// Counter-based RNG replacing the reference's racy global xorshf96
+// (utils.cpp:11-25); identical integer arithmetic to oracle/vrc_oracle.c.
+__device__ __forceinline__ uint32_t mix32(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x7feb352du;
+    x ^= x >> 15; x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ uint32_t counter_rand(uint32_t seed, uint32_t frame, uint32_t pixel, uint32_t draw)
+{
+    uint32_t h = mix32(seed ^ (frame * 0x9E3779B1u));
+    h = mix32(h ^ (pixel * 0x85EBCA77u));
+    h = mix32(h ^ (draw * 0xC2B2AE3Du) ^ 0x27D4EB2Fu);
+    return h;
+}
+// getRand (utils.cpp:77-81): 100 levels
+__device__ __forceinline__ float get_rand(uint32_t k, float mn, float mx)
+{
+    const float rand_val = (float)(k % 100u) / 100.0f;
+    return mn + (mx - mn) * rand_val;
+}
+
+constexpr int SVO_MAX = 23;  // lsvo.hpp:37
+
+// Traversal state of one ray (one lane).  LSVO<N>::castRay, lsvo.hpp:33-172.
+struct Ray {
+    float tcx, tcy, tcz;      // t_coef   :47
+    float tox, toy, toz;      // t_offset :48-52
+    float px, py, pz;         // pos      :63
+    float t_min, t_max, h;    // :54-58
+    float scale_f;            // :64
+    uint32_t parent_id;       // :60
+    int scale;                // :62 (int8_t in the reference; values stay in [0,23])
+    uint32_t child_offset;    // :61
+    uint32_t mirror;          // :49
+    uint32_t normal;          // :69 last step mask
+    uint32_t complexity;      // HitPoint::complexity :73
+    uint32_t kind;            // 0 = running / miss, 1 = leaf hit, 2 = LOD cut
+    uint32_t shift;           // child_shift at the hit
+    uint2 nd;                 // raw_data[parent_id], reloaded only when parent_id changes
+};
+
+// lsvo.hpp:36-70.  (dx,dy,dz) is conditioned in place (:44-46).  Returns
+// whether the loop condition of :72 holds (always true: scale = 22).
+__device__ __forceinline__ void ray_setup(Ray& r, const uint2* __restrict__ nodes,
+                                          float ox, float oy, float oz, float& dx, float& dy, float& dz)
+{
+    const float EPS = 1.0f / (float)(1 << SVO_MAX);
+    if (fabsf(dx) < EPS) dx = copysignf(EPS, dx);
+    if (fabsf(dy) < EPS) dy = copysignf(EPS, dy);
+    if (fabsf(dz) < EPS) dz = copysignf(EPS, dz);
+    r.tcx = -1.0f / fabsf(dx); r.tcy = -1.0f / fabsf(dy); r.tcz = -1.0f / fabsf(dz);
+    r.tox = ox * r.tcx; r.toy = oy * r.tcy; r.toz = oz * r.tcz;
+    r.mirror = 7u;
+    if (dx > 0.0f) { r.mirror ^= 1u; r.tox = 3.0f * r.tcx - r.tox; }
+    if (dy > 0.0f) { r.mirror ^= 2u; r.toy = 3.0f * r.tcy - r.toy; }
+    if (dz > 0.0f) { r.mirror ^= 4u; r.toz = 3.0f * r.tcz - r.toz; }
+    r.t_min = smax(2.0f * r.tcx - r.tox, smax(2.0f * r.tcy - r.toy, 2.0f * r.tcz - r.toz));
+    r.t_max = smin(r.tcx - r.tox, smin(r.tcy - r.toy, r.tcz - r.toz));
+    r.h = r.t_max;
+    r.t_min = smax(0.0f, r.t_min);
+    r.t_max = smin(1.0f, r.t_max);
+    r.parent_id = 0u;
+    r.child_offset = 0u;
+    r.scale = SVO_MAX - 1;
+    r.px = 1.0f; r.py = 1.0f; r.pz = 1.0f;
+    r.scale_f = 0.5f;
+    if (1.5f * r.tcx - r.tox > r.t_min) { r.child_offset ^= 1u; r.px = 1.5f; }
+    if (1.5f * r.tcy - r.toy > r.t_min) { r.child_offset ^= 2u; r.py = 1.5f; }
+    if (1.5f * r.tcz - r.toz > r.t_min) { r.child_offset ^= 4u; r.pz = 1.5f; }
+    r.normal = 0u;
+    r.complexity = 0u;
+    r.kind = 0u;
+    r.shift = 0u;
+    r.nd = nodes[0];
+}
+
+// One iteration of the while loop at lsvo.hpp:72-146.  `stk` points at this
+// lane's column of the LDS stack, `stride` = lanes per row, so slot s lives at
+// stk[s*stride]; slots are (scale - DEPTH_OFFSET - 1) in [0, depth-2].
+// Returns the loop condition for the next iteration.
+__device__ __forceinline__ bool ray_step(Ray& r, const uint2* __restrict__ nodes, uint2* stk, int stride,
+                                         int depth, float coef, float bias)
+{
+    const int depth_off = SVO_MAX - depth;
+    ++r.complexity;                                                     // :73
+    const uint2 nd = r.nd;                                              // :74
+    const float cx = r.px * r.tcx - r.tox;                              // :76
+    const float cy = r.py * r.tcy - r.toy;
+    const float cz = r.pz * r.tcz - r.toz;
+    const float tc_max = smin(cx, smin(cy, cz));                        // :77
+    const uint32_t child_shift = r.child_offset ^ r.mirror;            // :79
+    const uint32_t masks = nd.x >> child_shift;                         // bit 8: child, bit 16: leaf
+    if ((masks & 0x100u) && r.t_min <= r.t_max) {                       // :81
+        if (tc_max * coef + bias >= r.scale_f) {                        // :82-85
+            r.kind = 2u; r.shift = child_shift;
+            return false;
+        }
+        const float tv_max = smin(r.t_max, tc_max);                     // :86
+        const float half = r.scale_f * 0.5f;                            // :87
+        const float thx = half * r.tcx + cx;                            // :88
+        const float thy = half * r.tcy + cy;
+        const float thz = half * r.tcz + cz;
+        if (r.t_min <= tv_max) {                                        // :89
+            if (masks & 0x10000u) {                                     // :90-95
+                r.kind = 1u; r.shift = child_shift;
+                return false;
+            }
+            if (tc_max < r.h)                                           // :97-100
+                stk[(r.scale - depth_off - 1) * stride] = make_uint2(r.parent_id, f2u(r.t_max));
+            r.h = tc_max;                                               // :101
+            r.parent_id += nd.y + child_shift;                          // :103
+            r.nd = nodes[r.parent_id];
+            r.child_offset = 0u;
+            --r.scale;
+            r.scale_f = half;
+            if (thx > r.t_min) { r.child_offset ^= 1u; r.px += r.scale_f; }   // :107-109
+            if (thy > r.t_min) { r.child_offset ^= 2u; r.py += r.scale_f; }
+            if (thz > r.t_min) { r.child_offset ^= 4u; r.pz += r.scale_f; }
+            r.t_max = tv_max;                                           // :110
+            return r.scale > depth;                                     // :72 (scale < 23 holds)
+        }
+    }
+    uint32_t step_mask = 0u;                                            // :115-118
+    if (cx <= tc_max) { step_mask ^= 1u; r.px -= r.scale_f; }
+    if (cy <= tc_max) { step_mask ^= 2u; r.py -= r.scale_f; }
+    if (cz <= tc_max) { step_mask ^= 4u; r.pz -= r.scale_f; }
+    r.t_min = tc_max;                                                   // :120
+    r.child_offset ^= step_mask;                                        // :121
+    r.normal = step_mask;                                               // :122
+    if (r.child_offset & step_mask) {                                   // :124 pop
+        uint32_t differing_bits = 0u;
+        const uint32_t ipx = f2u(r.px), ipy = f2u(r.py), ipz = f2u(r.pz);
+        if (step_mask & 1u) differing_bits |= ipx ^ f2u(r.px + r.scale_f);
+        if (step_mask & 2u) differing_bits |= ipy ^ f2u(r.py + r.scale_f);
+        if (step_mask & 4u) differing_bits |= ipz ^ f2u(r.pz + r.scale_f);
+        // :132 -- exponent of (float)differing_bits.  pos stays in [0.5, 2) so
+        // differing_bits < 2^24 converts exactly and the exponent is the index
+        // of the highest set bit.  differing_bits == 0 (unreachable, UB in the
+        // reference) yields scale = -1 and ends the walk as a miss.
+        r.scale = 31 - __clz((int)differing_bits);
+        if (r.scale >= SVO_MAX || r.scale <= depth) {
+            // ray left the root (scale == 23): the reference reads the never
+            // written stack[N] here and then leaves the loop (App. A.9).
+            return false;
+        }
+        r.scale_f = u2f((uint32_t)(r.scale - SVO_MAX + 127) << SVO_MAX);  // :133
+        const uint2 entry = stk[(r.scale - depth_off - 1) * stride];     // :134-136
+        r.parent_id = entry.x;
+        r.nd = nodes[r.parent_id];
+        r.t_max = u2f(entry.y);
+        const uint32_t shx = ipx >> r.scale, shy = ipy >> r.scale, shz = ipz >> r.scale;  // :137-143
+        r.px = u2f(shx << r.scale); r.py = u2f(shy << r.scale); r.pz = u2f(shz << r.scale);
+        r.child_offset = (shx & 1u) | ((shy & 1u) << 1u) | ((shz & 1u) << 2u);
+        r.h = 0.0f;                                                      // :144
+    }
+    return true;
+}
+
+struct Hit {
+    float px, py, pz;     // position
+    float nx, ny, nz;     // normal
+    float u, v;           // voxel_coord
+    float distance;
+    uint32_t hit;         // kind | shift<<8 | scale<<16
+    uint32_t node;
+    uint32_t complexity;
+};
+
+// lsvo.hpp:148-169 epilogue.  (ox..) = ray origin, (dx..) = conditioned direction.
+__device__ __forceinline__ void ray_finish(const Ray& r, int depth, float ox, float oy, float oz,
+                                           float dx, float dy, float dz, Hit& out)
+{
+    out.px = out.py = out.pz = 0.0f;
+    out.nx = out.ny = out.nz = 0.0f;
+    out.u = out.v = 0.0f;
+    out.distance = 0.0f;
+    out.hit = 0u; out.node = 0u;
+    out.complexity = r.complexity;
+    if (!r.kind) return;
+    const float EPS = 1.0f / (float)(1 << SVO_MAX);
+    const float SVO_SIZE = (float)(1 << depth);
+    // :149  -sign(d) * (float(normal&1), float(normal&2), float(normal&4)); d != 0 after conditioning
+    out.nx = ((dx > 0.0f) ? -1.0f : ((dx < 0.0f) ? 1.0f : -0.0f)) * (float)(r.normal & 1u);
+    out.ny = ((dy > 0.0f) ? -1.0f : ((dy < 0.0f) ? 1.0f : -0.0f)) * (float)(r.normal & 2u);
+    out.nz = ((dz > 0.0f) ? -1.0f : ((dz < 0.0f) ? 1.0f : -0.0f)) * (float)(r.normal & 4u);
+    float qx = r.px, qy = r.py, qz = r.pz;
+    if ((r.mirror & 1u) == 0u) qx = 3.0f - r.scale_f - qx;               // :151-153
+    if ((r.mirror & 2u) == 0u) qy = 3.0f - r.scale_f - qy;
+    if ((r.mirror & 4u) == 0u) qz = 3.0f - r.scale_f - qz;
+    out.distance = r.t_min;                                              // :155
+    out.px = smin(smax(ox + r.t_min * dx, qx + EPS), qx + r.scale_f - EPS);  // :156-158
+    out.py = smin(smax(oy + r.t_min * dy, qy + EPS), qy + r.scale_f - EPS);
+    out.pz = smin(smax(oz + r.t_min * dz, qz + EPS), qz + r.scale_f - EPS);
+    if (out.nx != 0.0f) {                                                // :160-168
+        out.u = fracf_(out.pz * SVO_SIZE); out.v = fracf_(out.py * SVO_SIZE);
+    } else if (out.ny != 0.0f) {
+        out.u = fracf_(out.px * SVO_SIZE); out.v = fracf_(out.pz * SVO_SIZE);
+    } else if (out.nz != 0.0f) {
+        out.u = fracf_(out.px * SVO_SIZE); out.v = fracf_(out.py * SVO_SIZE);
+    }
+    out.hit = r.kind | (r.shift << 8) | ((uint32_t)(r.scale & 0xff) << 16);
+    out.node = r.parent_id;
+}
+
+}  // namespace vrc

@@ -1,0 +1,42 @@
+// vrc_internal.h -- shared between vrc_kernels.hip (device + launchers) and
+// vrc_api.cpp (C ABI).  Not part of the public interface.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vrc.h"
+
+#define VRC_RENDER_BLOCK 256
+
+namespace vrc {
+
+// by-value kernel argument of k_render
+struct FrameArgs {
+    const uint2* nodes;       // LNode[] (8 B each)
+    const uint8_t* tex;       // 1536 B: top table then side table
+    uint8_t* image;           // RGBA8 w*h
+    uint32_t* accum;          // 4 x u32 per pixel
+    vrc_hit* prim;            // optional primary-hit capture
+    uint64_t* stats;          // rays, sum_complexity, primary_hits, pixels
+    uint32_t* queue;          // work-queue head
+    uint32_t depth, width, height;
+    uint32_t n_items;         // work items (8x8-tile order over this shard's rows)
+    uint32_t chunk;           // items a wave takes from the queue at once
+    uint32_t refill_threshold;// leave the traversal loop once this many lanes wait
+    vrc_camera cam;
+    vrc_frame_params p;
+};
+
+hipError_t launch_cast_rays(const void* nodes, int depth, uint64_t n, const float* org, const float* dir,
+                            const float* coef, const float* bias, vrc_hit* out, hipStream_t st);
+hipError_t launch_grid_cast(const uint8_t* cells, int X, int Y, int Z, uint64_t n, const float* org, const float* dir,
+                            vrc_hit* out, hipStream_t st);
+hipError_t launch_render(const FrameArgs& a, uint32_t grid_blocks, hipStream_t st);
+hipError_t launch_resolve(const void* accum, void* image, uint32_t n, hipStream_t st);
+hipError_t launch_fill_u32(void* p, uint32_t value, uint64_t n, hipStream_t st);
+hipError_t launch_pack_shard(const void* image, uint32_t W, uint32_t H, uint32_t row_block, uint32_t shard,
+                             uint32_t count, uint32_t slots, void* dst, hipStream_t st);
+hipError_t launch_unpack_shards(const void* gathered, uint32_t W, uint32_t H, uint32_t row_block, uint32_t count,
+                                uint32_t slots, void* image, hipStream_t st);
+
+}  // namespace vrc

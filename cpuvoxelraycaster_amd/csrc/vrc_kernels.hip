@@ -1,0 +1,568 @@
+// vrc_kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4, wave64) for the
+// voxel ray-traversal hot path, plus their launchers.
+//
+//   k_cast_rays   T1   batch LSVO<N>::castRay (lsvo.hpp:33-172), one lane per ray
+//   k_render      R0 + S1..S4  persistent-threads frame kernel: every lane runs a
+//                 small state machine primary -> shadow -> GI -> GI-shadow over ONE
+//                 shared traversal loop, lanes that run out of rays are refilled
+//                 from a work queue by wave ballot / prefix-sum (mbcnt)
+//   k_grid_cast   G1   Grid3D::castRay (grid_3d.hpp:36-132)
+//   k_resolve / k_fill / k_pack / k_unpack   S4 sink + multi-GPU shard plumbing
+//
+// No MFMA anywhere: this is dependent 8-byte gathers, not a contraction.
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see build.py).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vrc.h"
+#include "vrc_device.h"
+#include "vrc_internal.h"
+
+using namespace vrc;
+
+// ---------------------------------------------------------------------------
+// T1: batch per-ray operator
+// ---------------------------------------------------------------------------
+
+extern "C" __global__ void __launch_bounds__(256)
+k_cast_rays(const uint2* __restrict__ nodes, int depth, uint64_t n,
+            const float* __restrict__ org, const float* __restrict__ dir,
+            const float* __restrict__ coef_a, const float* __restrict__ bias_a,
+            vrc_hit* __restrict__ out)
+{
+    extern __shared__ uint2 lds_stack[];  // [depth-1][blockDim.x]
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float ox = org[3 * i + 0], oy = org[3 * i + 1], oz = org[3 * i + 2];
+    float dx = dir[3 * i + 0], dy = dir[3 * i + 1], dz = dir[3 * i + 2];
+    const float coef = coef_a ? coef_a[i] : 0.0f;
+    const float bias = bias_a ? bias_a[i] : 0.0f;
+    Ray r;
+    ray_setup(r, nodes, ox, oy, oz, dx, dy, dz);
+    uint2* stk = lds_stack + threadIdx.x;
+    const int stride = blockDim.x;
+    bool active = true;
+    while (active) active = ray_step(r, nodes, stk, stride, depth, coef, bias);
+    Hit h;
+    ray_finish(r, depth, ox, oy, oz, dx, dy, dz, h);
+    // 48-byte record as three 16-byte stores
+    uint4* o = reinterpret_cast<uint4*>(out + i);
+    o[0] = make_uint4(f2u(h.px), f2u(h.py), f2u(h.pz), f2u(h.nx));
+    o[1] = make_uint4(f2u(h.ny), f2u(h.nz), f2u(h.u), f2u(h.v));
+    o[2] = make_uint4(h.hit, h.node, f2u(h.distance), h.complexity);
+}
+
+// ---------------------------------------------------------------------------
+// G1: dense grid DDA
+// ---------------------------------------------------------------------------
+
+extern "C" __global__ void __launch_bounds__(256)
+k_grid_cast(const uint8_t* __restrict__ cells, int X, int Y, int Z, uint64_t n,
+            const float* __restrict__ org, const float* __restrict__ dir, vrc_hit* __restrict__ out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float ox = org[3 * i + 0], oy = org[3 * i + 1], oz = org[3 * i + 2];
+    const float dx = dir[3 * i + 0], dy = dir[3 * i + 1], dz = dir[3 * i + 2];
+    // grid_3d.hpp:42-64
+    const float t_dx = fabsf(1.0f / dx), t_dy = fabsf(1.0f / dy), t_dz = fabsf(1.0f / dz);
+    const int step_x = dx < 0 ? -1 : 1, step_y = dy < 0 ? -1 : 1, step_z = dz < 0 ? -1 : 1;
+    const int dir_x = step_x > 0 ? 1 : 0, dir_y = step_y > 0 ? 1 : 0, dir_z = step_z > 0 ? 1 : 0;
+    int cell_x = (int)ox, cell_y = (int)oy, cell_z = (int)oz;
+    float t_max_x = ((float)(cell_x + dir_x) - ox) / dx;
+    float t_max_y = ((float)(cell_y + dir_y) - oy) / dy;
+    float t_max_z = ((float)(cell_z + dir_z) - oz) / dz;
+    uint32_t hit_side = 0, iter = 0, hit = 0, node = 0;
+    float hx = 0, hy = 0, hz = 0, nx = 0, ny = 0, nz = 0, u = 0, v = 0, dist = 0;
+    uint32_t complexity = 0;
+    // :70
+    while (cell_x >= 0 && cell_y >= 0 && cell_z >= 0 && cell_x < X && cell_y < Y && cell_z < Z && iter < 2048u) {
+        float t_max_min;
+        ++iter;
+        if (t_max_x < t_max_y) {  // :73-100
+            if (t_max_x < t_max_z) { t_max_min = t_max_x; t_max_x += t_dx; cell_x += step_x; hit_side = 0; }
+            else                   { t_max_min = t_max_z; t_max_z += t_dz; cell_z += step_z; hit_side = 2; }
+        } else {
+            if (t_max_y < t_max_z) { t_max_min = t_max_y; t_max_y += t_dy; cell_y += step_y; hit_side = 1; }
+            else                   { t_max_min = t_max_z; t_max_z += t_dz; cell_z += step_z; hit_side = 2; }
+        }
+        if (cell_x >= 0 && cell_y >= 0 && cell_z >= 0 && cell_x < X && cell_y < Y && cell_z < Z) {  // :102
+            const int64_t idx = ((int64_t)cell_x * Y + cell_y) * Z + cell_z;
+            if (cells[idx] != 0) {
+                hx = ox + t_max_min * dx; hy = oy + t_max_min * dy; hz = oz + t_max_min * dz;
+                hit = 1u | (hit_side << 8); node = (uint32_t)idx;
+                if (hit_side == 0)      { nx = (float)(-step_x); u = 1.0f - fracf_(hz); v = fracf_(hy); }
+                else if (hit_side == 1) { ny = (float)(-step_y); u = fracf_(hx); v = fracf_(hz); }
+                else                    { nz = (float)(-step_z); u = fracf_(hx); v = fracf_(hy); }
+                dist = t_max_min; complexity = iter;
+                break;
+            }
+        }
+    }
+    uint4* o = reinterpret_cast<uint4*>(out + i);
+    o[0] = make_uint4(f2u(hx), f2u(hy), f2u(hz), f2u(nx));
+    o[1] = make_uint4(f2u(ny), f2u(nz), f2u(u), f2u(v));
+    o[2] = make_uint4(hit, node, f2u(dist), complexity);
+}
+
+// ---------------------------------------------------------------------------
+// R0 + S1..S4: persistent-threads frame kernel
+// ---------------------------------------------------------------------------
+
+namespace {
+
+enum Stage : uint32_t {
+    ST_NEED_WORK = 0,  // lane has no pixel
+    ST_PRIMARY = 1,    // raycaster.hpp:131
+    ST_SHADOW = 2,     // raycaster.hpp:153
+    ST_GI = 3,         // raycaster.hpp:194
+    ST_GI_SHADOW = 4,  // raycaster.hpp:198
+    ST_DONE = 5,       // queue exhausted
+};
+
+// utils.cpp:43-48 on a packed 0x00BBGGRR colour
+__device__ __forceinline__ uint32_t color_mult(uint32_t c, float f)
+{
+    const uint32_t r = (uint32_t)smin(255.0f, (float)(c & 0xffu) * f);
+    const uint32_t g = (uint32_t)smin(255.0f, (float)((c >> 8) & 0xffu) * f);
+    const uint32_t b = (uint32_t)smin(255.0f, (float)((c >> 16) & 0xffu) * f);
+    return r | (g << 8) | (b << 16);
+}
+// utils.cpp:35-40
+__device__ __forceinline__ uint32_t color_add_sat(uint32_t a, uint32_t b)
+{
+    const uint32_t r = min(255u, (a & 0xffu) + (b & 0xffu));
+    const uint32_t g = min(255u, ((a >> 8) & 0xffu) + ((b >> 8) & 0xffu));
+    const uint32_t bl = min(255u, ((a >> 16) & 0xffu) + ((b >> 16) & 0xffu));
+    return r | (g << 8) | (bl << 16);
+}
+// utils.cpp:67-75
+__device__ __forceinline__ float clampf_(float v, float mn, float mx)
+{
+    if (v > mx) v = mx; else if (v < mn) v = mn;
+    return v;
+}
+
+// main.cpp:131-132,140-143 + shard ownership (same predicate as the oracle's pixel_selected)
+__device__ __forceinline__ bool pixel_selected(const vrc_frame_params& p, uint32_t W, uint32_t H, uint32_t x, uint32_t y)
+{
+    if (p.checker_parity >= 0) {
+        const uint32_t aw = W / 4u, ah = H / 4u;
+        if (aw == 0u || ah == 0u || x >= 4u * aw || y >= 4u * ah) return false;
+        const uint32_t y0 = (y / ah) * ah;
+        if (((y - y0) % 2u) != ((x + (uint32_t)p.checker_parity) % 2u)) return false;
+    }
+    return true;
+}
+
+}  // namespace
+
+extern "C" __global__ void __launch_bounds__(VRC_RENDER_BLOCK)
+k_render(const FrameArgs a)
+{
+    extern __shared__ uint2 lds_dyn[];                 // [depth-1][VRC_RENDER_BLOCK] stack, then 1536 B textures
+    const int stride = VRC_RENDER_BLOCK;
+    uint2* stk = lds_dyn + threadIdx.x;
+    uint8_t* tex = reinterpret_cast<uint8_t*>(lds_dyn + (a.depth - 1) * VRC_RENDER_BLOCK);
+    for (uint32_t i = threadIdx.x; i < 1536u / 4u; i += VRC_RENDER_BLOCK)
+        reinterpret_cast<uint32_t*>(tex)[i] = reinterpret_cast<const uint32_t*>(a.tex)[i];
+    __syncthreads();
+
+    const uint2* __restrict__ nodes = a.nodes;
+    const int depth = (int)a.depth;
+    const uint32_t W = a.width, H = a.height;
+    const float inv_size = 1.0f / (float)(1u << a.depth);                 // main.cpp:82
+    const float n_normalizer = inv_size * 0.0078125f * 2.0f;              // raycaster.hpp:171-172
+    const float lx = a.p.light_position[0], ly = a.p.light_position[1], lz = a.p.light_position[2];
+    const uint32_t shadow_samples = a.p.shadow_samples ? a.p.shadow_samples : (a.p.use_samples ? 4u : 1u);
+    const uint32_t gi_bounces = a.p.gi_bounces ? a.p.gi_bounces : 1u;
+    const uint32_t spp = a.p.spp ? a.p.spp : 1u;
+    const uint32_t tiles_per_row = (W + 7u) / 8u;
+
+    // wave-uniform work chunk [cur, end)
+    uint32_t cur = 0u, end = 0u;
+    bool exhausted = false;
+
+    // per-lane pixel program state
+    uint32_t stage = ST_NEED_WORK;
+    uint32_t pix = 0u, px_x = 0u, px_y = 0u, sample = 0u;
+    uint32_t acc_r = 0u, acc_g = 0u, acc_b = 0u;   // this pixel's colour summed over the samples of this call
+    uint32_t last_color = 0u;
+    uint32_t albedo = 0u;
+    float base_px = 0, base_py = 0, base_pz = 0;   // point the next GI ray starts from
+    float base_nx = 0, base_ny = 0, base_nz = 0;
+    float light_intensity = 0.0f;
+    float pending = 0.0f;                           // value applied if the current shadow-type ray is unoccluded
+    float dot_gi = 0.0f, dot_gi0 = 0.0f, acc0 = 0.0f, acc1 = 0.0f;
+    uint32_t shadow_left = 0u, gi_level = 0u, draw = 0u;
+    // current ray
+    Ray r;
+    float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, coef = 0.0f;
+    bool active = false;
+    // stats
+    uint32_t n_rays = 0u, n_steps = 0u, n_hits = 0u, n_pix = 0u;
+
+    for (;;) {
+        // ------------------------------------------------------------------
+        // traversal phase: step every active lane until enough lanes wait
+        // ------------------------------------------------------------------
+        for (;;) {
+            const uint64_t act = __ballot(active);
+            if (act == 0ull) break;
+            const uint64_t waiting = __ballot(!active && stage != ST_DONE);
+            if ((uint32_t)__popcll(waiting) >= a.refill_threshold) break;
+            if (active) active = ray_step(r, nodes, stk, stride, depth, coef, 0.0f);
+        }
+
+        // ------------------------------------------------------------------
+        // transition phase: lanes whose ray ended consume the result
+        // ------------------------------------------------------------------
+        bool launch = false;        // a secondary ray (ox.., dx.., coef) is ready to start
+        bool gen_primary = false;   // generate the next sample's camera ray for (px_x, px_y)
+        bool sample_done = false;
+        uint32_t final_color = 0u;
+        if (!active && stage >= ST_PRIMARY && stage <= ST_GI_SHADOW) {
+            n_rays += 1u;
+            n_steps += r.complexity;
+            if (stage == ST_PRIMARY) {
+                Hit h;
+                ray_finish(r, depth, ox, oy, oz, dx, dy, dz, h);
+                if (a.prim && sample == 0u) {
+                    uint4* o = reinterpret_cast<uint4*>(a.prim + pix);
+                    o[0] = make_uint4(f2u(h.px), f2u(h.py), f2u(h.pz), f2u(h.nx));
+                    o[1] = make_uint4(f2u(h.ny), f2u(h.nz), f2u(h.u), f2u(h.v));
+                    o[2] = make_uint4(h.hit, h.node, f2u(h.distance), h.complexity);
+                }
+                if (!h.hit) {                                            // raycaster.hpp:135 miss -> Black
+                    sample_done = true; final_color = 0u;
+                } else {
+                    n_hits += 1u;
+                    // raycaster.hpp:209-240 albedo
+                    const uint8_t* img = (h.ny != 0.0f) ? tex : tex + 768;
+                    const float tu = clampf_(h.u, 0.0f, 1.0f), tv = clampf_(h.v, 0.0f, 1.0f);
+                    uint32_t idx = (uint32_t)(16.0f * tu) + (uint32_t)(16.0f * tv) * 16u;
+                    idx = min(idx, 255u);
+                    albedo = (uint32_t)img[idx * 3] | ((uint32_t)img[idx * 3 + 1] << 8) | ((uint32_t)img[idx * 3 + 2] << 16);
+                    base_px = h.px; base_py = h.py; base_pz = h.pz;
+                    base_nx = h.nx; base_ny = h.ny; base_nz = h.nz;
+                    // raycaster.hpp:139,150-153 shadow ray
+                    ox = h.px + h.nx * inv_size * 0.001f;
+                    oy = h.py + h.ny * inv_size * 0.001f;
+                    oz = h.pz + h.nz * inv_size * 0.001f;
+                    dx = lx - ox; dy = ly - oy; dz = lz - oz;
+                    normalize3(dx, dy, dz);
+                    pending = smax(0.0f, dot3(dx, dy, dz, h.nx, h.ny, h.nz));   // :156
+                    light_intensity = 0.0f;
+                    shadow_left = shadow_samples;
+                    coef = 0.0f;
+                    stage = ST_SHADOW;
+                    launch = true;
+                }
+            } else if (stage == ST_SHADOW) {
+                if (!r.kind) light_intensity = pending;                  // :155-157
+                shadow_left -= 1u;
+                if (shadow_left != 0u) {
+                    // the reference re-casts the identical ray (jitter commented out, :151)
+                    dx = lx - ox; dy = ly - oy; dz = lz - oz;
+                    normalize3(dx, dy, dz);
+                    launch = true;
+                } else if (a.p.use_gi) {
+                    gi_level = 0u; acc0 = 0.0f; acc1 = 0.0f;
+                    stage = ST_GI;      // ray generated below
+                } else {
+                    sample_done = true;
+                    final_color = color_mult(albedo, smin(1.0f, smax(0.0f, light_intensity + 0.0f)));  // :161-163
+                }
+            } else if (stage == ST_GI) {
+                Hit g;
+                ray_finish(r, depth, ox, oy, oz, dx, dy, dz, g);
+                if (g.hit) {                                             // raycaster.hpp:195-198
+                    base_px = g.px; base_py = g.py; base_pz = g.pz;
+                    base_nx = g.nx; base_ny = g.ny; base_nz = g.nz;
+                    ox = g.px + g.nx * n_normalizer;
+                    oy = g.py + g.ny * n_normalizer;
+                    oz = g.pz + g.nz * n_normalizer;
+                    dx = lx - ox; dy = ly - oy; dz = lz - oz;
+                    normalize3(dx, dy, dz);
+                    const float dotl = dot3(g.nx, g.ny, g.nz, dx, dy, dz);                     // :200
+                    pending = 1000000.0f * smin(0.5f, smax(0.0f, dotl) * dot_gi);              // :201
+                    coef = 0.5f;
+                    stage = ST_GI_SHADOW;
+                    launch = true;
+                } else {
+                    stage = ST_NEED_WORK + 100u;  // GI chain ends here
+                }
+            } else {  // ST_GI_SHADOW
+                if (gi_level == 0u) { if (!r.kind) acc0 += pending; }
+                else                { if (!r.kind) acc1 += pending; }
+                if (gi_level + 1u < gi_bounces) {
+                    dot_gi0 = dot_gi; gi_level += 1u;
+                    stage = ST_GI;      // extension: next bounce starts from the GI hit (base_*)
+                } else {
+                    stage = ST_NEED_WORK + 100u;
+                }
+            }
+            if (stage == ST_GI) {
+                // raycaster.hpp:174-194: GI ray from (base_p, base_n)
+                ox = base_px + base_nx * n_normalizer;
+                oy = base_py + base_ny * n_normalizer;
+                oz = base_pz + base_nz * n_normalizer;
+                const float c1 = get_rand(counter_rand(a.p.seed, a.p.frame_index + sample, pix, draw), -1000.0f, 1000.0f);
+                const float c2 = get_rand(counter_rand(a.p.seed, a.p.frame_index + sample, pix, draw + 1u), -1000.0f, 1000.0f);
+                draw += 2u;
+                float qx = 0.0f, qy = 0.0f, qz = 0.0f;
+                if (base_nx != 0.0f)      { qy = c1; qz = c2; }
+                else if (base_ny != 0.0f) { qx = c1; qz = c2; }
+                else if (base_nz != 0.0f) { qx = c1; qy = c2; }
+                dx = (base_nx + qx) * n_normalizer;
+                dy = (base_ny + qy) * n_normalizer;
+                dz = (base_nz + qz) * n_normalizer;
+                normalize3(dx, dy, dz);
+                dot_gi = dot3(dx, dy, dz, base_nx, base_ny, base_nz);    // :193
+                coef = 0.5f;
+                launch = true;
+            } else if (stage == ST_NEED_WORK + 100u) {
+                // raycaster.hpp:206 + nested extension: gi = max(0, acc0 [+ dot_gi0 * max(0, acc1)])
+                float gi;
+                if (gi_level == 0u) gi = smax(0.0f, acc0 / 1.0f);
+                else { acc0 += dot_gi0 * smax(0.0f, acc1 / 1.0f); gi = smax(0.0f, acc0 / 1.0f); }
+                sample_done = true;
+                final_color = color_mult(albedo, smin(1.0f, smax(0.0f, light_intensity + gi)));   // :163
+            }
+            if (sample_done) {
+                n_pix += 1u;
+                if (a.p.use_samples) { acc_r += final_color & 0xffu; acc_g += (final_color >> 8) & 0xffu; acc_b += (final_color >> 16) & 0xffu; }
+                else {
+                    // raycaster.hpp:77-85 temporal blend against the stored pixel
+                    uint32_t old = reinterpret_cast<uint32_t*>(a.image)[pix];
+                    const uint32_t alpha = old & 0xff000000u;
+                    old = color_mult(old & 0xffffffu, 0.4f);
+                    const uint32_t nw = color_mult(final_color, 1.0f - 0.4f);
+                    reinterpret_cast<uint32_t*>(a.image)[pix] = color_add_sat(old, nw) | alpha;
+                }
+                sample += 1u;
+                if (sample < spp) { gen_primary = true; }
+                else {
+                    if (a.p.use_samples) {
+                        uint4* ap = reinterpret_cast<uint4*>(a.accum) + pix;   // raycaster.hpp:87-90
+                        uint4 v = *ap;
+                        v.x += acc_r; v.y += acc_g; v.z += acc_b; v.w += spp;
+                        *ap = v;
+                    }
+                    stage = ST_NEED_WORK;
+                }
+            }
+        }
+
+        // ------------------------------------------------------------------
+        // refill: lanes without a pixel take consecutive work items
+        // ------------------------------------------------------------------
+        {
+            bool need = (stage == ST_NEED_WORK);
+            uint64_t mask = __ballot(need);
+            while (mask != 0ull && !exhausted) {
+                if (cur >= end) {
+                    uint32_t base = 0u;
+                    if (__lane_id() == 0u) base = atomicAdd(a.queue, a.chunk);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (base >= a.n_items) { exhausted = true; break; }
+                    cur = base;
+                    end = min(base + a.chunk, a.n_items);
+                }
+                const uint32_t avail = end - cur;
+                const uint32_t cnt = (uint32_t)__popcll(mask);
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                if (need && rank < avail) {
+                    const uint32_t item = cur + rank;
+                    const uint32_t t = item >> 6, l = item & 63u;
+                    const uint32_t tx = t % tiles_per_row, ty = t / tiles_per_row;
+                    const uint32_t x = tx * 8u + (l & 7u);
+                    uint32_t y = ty * 8u + (l >> 3);
+                    if (a.p.row_block && a.p.shard_count > 1u)
+                        y = ((y / a.p.row_block) * a.p.shard_count + a.p.shard_index) * a.p.row_block + (y % a.p.row_block);
+                    if (x < W && y < H && pixel_selected(a.p, W, H, x, y)) {
+                        px_x = x; px_y = y; pix = y * W + x;
+                        sample = 0u; acc_r = acc_g = acc_b = 0u;
+                        stage = ST_PRIMARY;
+                        gen_primary = true;
+                    }
+                }
+                cur += min(cnt, avail);
+                need = (stage == ST_NEED_WORK);
+                mask = __ballot(need);
+            }
+            if (exhausted && stage == ST_NEED_WORK) stage = ST_DONE;
+        }
+
+        // ------------------------------------------------------------------
+        // R0: camera ray for (px_x, px_y), sample `sample`
+        // (main.cpp:133,145-149; camera_controller.hpp:34-54)
+        // ------------------------------------------------------------------
+        if (gen_primary) {
+            const float aspect_ratio = (float)W / (float)H;
+            const float lens_x = (float)px_x / (float)H - aspect_ratio * 0.5f;
+            const float lens_y = (float)px_y / (float)H - 0.5f;
+            float sx = lens_x, sy = lens_y, sz = a.cam.fov;
+            normalize3(sx, sy, sz);
+            const float fx = sx * a.cam.focal_length, fy = sy * a.cam.focal_length, fz = sz * a.cam.focal_length;
+            const uint32_t fr = a.p.frame_index + sample;
+            const float r0 = get_rand(counter_rand(a.p.seed, fr, pix, 0u), -0.5f, 0.5f);
+            const float r1 = get_rand(counter_rand(a.p.seed, fr, pix, 1u), -0.5f, 0.5f);
+            draw = 2u;
+            const float rvx = a.cam.aperture * r0, rvy = a.cam.aperture * r1, rvz = a.cam.aperture * 0.0f;
+            float vx = fx - rvx, vy = fy - rvy, vz = fz - rvz;
+            normalize3(vx, vy, vz);
+            const float* m = a.cam.rot;
+            dx = (m[0] * vx + m[1] * vy) + m[2] * vz;
+            dy = (m[3] * vx + m[4] * vy) + m[5] * vz;
+            dz = (m[6] * vx + m[7] * vy) + m[8] * vz;
+            const float wx = (m[0] * rvx + m[1] * rvy) + m[2] * rvz;
+            const float wy = (m[3] * rvx + m[4] * rvy) + m[5] * rvz;
+            const float wz = (m[6] * rvx + m[7] * rvy) + m[8] * rvz;
+            ox = (a.cam.position[0] + wx) * inv_size + 1.0f;
+            oy = (a.cam.position[1] + wy) * inv_size + 1.0f;
+            oz = (a.cam.position[2] + wz) * inv_size + 1.0f;
+            coef = 0.0f;
+            stage = ST_PRIMARY;
+            launch = true;
+        }
+        if (launch) {
+            ray_setup(r, nodes, ox, oy, oz, dx, dy, dz);
+            active = true;
+        }
+        if (__ballot(stage != ST_DONE) == 0ull) break;
+    }
+
+    // stats: wave reduction, one atomic per wave and counter
+    uint64_t s_rays = n_rays, s_steps = n_steps, s_hits = n_hits, s_pix = n_pix;
+    for (int off = 32; off > 0; off >>= 1) {
+        s_rays += __shfl_down(s_rays, off);
+        s_steps += __shfl_down(s_steps, off);
+        s_hits += __shfl_down(s_hits, off);
+        s_pix += __shfl_down(s_pix, off);
+    }
+    if (__lane_id() == 0u) {
+        atomicAdd(reinterpret_cast<unsigned long long*>(a.stats + 0), (unsigned long long)s_rays);
+        atomicAdd(reinterpret_cast<unsigned long long*>(a.stats + 1), (unsigned long long)s_steps);
+        atomicAdd(reinterpret_cast<unsigned long long*>(a.stats + 2), (unsigned long long)s_hits);
+        atomicAdd(reinterpret_cast<unsigned long long*>(a.stats + 3), (unsigned long long)s_pix);
+    }
+    (void)last_color;
+}
+
+// ---------------------------------------------------------------------------
+// S4 sink + plumbing
+// ---------------------------------------------------------------------------
+
+// raycaster.hpp:94-103: uint8(sum / count) in double == integer division for integer sums
+extern "C" __global__ void k_resolve(const uint4* __restrict__ accum, uint32_t* __restrict__ image, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint4 v = accum[i];
+    uint32_t c = 0u;
+    if (v.w) c = (v.x / v.w) | ((v.y / v.w) << 8) | ((v.z / v.w) << 16);
+    image[i] = c | 0xff000000u;
+}
+
+extern "C" __global__ void k_fill_u32(uint32_t* __restrict__ p, uint32_t value, uint64_t n)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = value;
+}
+
+// compact the row blocks owned by `shard` into dst: slot k <- block shard + k*count
+extern "C" __global__ void k_pack_shard(const uint32_t* __restrict__ image, uint32_t W, uint32_t H, uint32_t row_block,
+                                        uint32_t shard, uint32_t count, uint32_t slots, uint32_t* __restrict__ dst)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t per_slot = (uint64_t)row_block * W;
+    if (i >= per_slot * slots) return;
+    const uint32_t k = (uint32_t)(i / per_slot);
+    const uint64_t rem = i % per_slot;
+    const uint32_t y = (k * count + shard) * row_block + (uint32_t)(rem / W);
+    const uint32_t x = (uint32_t)(rem % W);
+    dst[i] = (y < H) ? image[(uint64_t)y * W + x] : 0u;
+}
+
+// inverse: gathered[shard][slot][row_block][W] -> image
+extern "C" __global__ void k_unpack_shards(const uint32_t* __restrict__ gathered, uint32_t W, uint32_t H, uint32_t row_block,
+                                           uint32_t count, uint32_t slots, uint32_t* __restrict__ image)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint64_t)W * H) return;
+    const uint32_t y = (uint32_t)(i / W), x = (uint32_t)(i % W);
+    const uint32_t b = y / row_block;
+    const uint32_t shard = b % count, k = b / count;
+    image[i] = gathered[(((uint64_t)shard * slots + k) * row_block + (y % row_block)) * W + x];
+}
+
+// ---------------------------------------------------------------------------
+// launchers (called from vrc_api.cpp through vrc_internal.h)
+// ---------------------------------------------------------------------------
+
+namespace vrc {
+
+hipError_t launch_cast_rays(const void* nodes, int depth, uint64_t n, const float* org, const float* dir,
+                            const float* coef, const float* bias, vrc_hit* out, hipStream_t st)
+{
+    if (n == 0) return hipSuccess;
+    const int block = 256;
+    const uint64_t grid = (n + block - 1) / block;
+    const size_t lds = (size_t)(depth - 1) * block * sizeof(uint2);
+    hipLaunchKernelGGL(k_cast_rays, dim3((uint32_t)grid), dim3(block), lds, st,
+                       (const uint2*)nodes, depth, n, org, dir, coef, bias, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_grid_cast(const uint8_t* cells, int X, int Y, int Z, uint64_t n, const float* org, const float* dir,
+                            vrc_hit* out, hipStream_t st)
+{
+    if (n == 0) return hipSuccess;
+    const int block = 256;
+    const uint64_t grid = (n + block - 1) / block;
+    hipLaunchKernelGGL(k_grid_cast, dim3((uint32_t)grid), dim3(block), 0, st, cells, X, Y, Z, n, org, dir, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_render(const FrameArgs& a, uint32_t grid_blocks, hipStream_t st)
+{
+    const size_t lds = (size_t)(a.depth - 1) * VRC_RENDER_BLOCK * sizeof(uint2) + 1536;
+    hipLaunchKernelGGL(k_render, dim3(grid_blocks), dim3(VRC_RENDER_BLOCK), lds, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_resolve(const void* accum, void* image, uint32_t n, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_resolve, dim3((n + 255) / 256), dim3(256), 0, st, (const uint4*)accum, (uint32_t*)image, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_fill_u32(void* p, uint32_t value, uint64_t n, hipStream_t st)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_fill_u32, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, (uint32_t*)p, value, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_shard(const void* image, uint32_t W, uint32_t H, uint32_t row_block, uint32_t shard,
+                             uint32_t count, uint32_t slots, void* dst, hipStream_t st)
+{
+    const uint64_t n = (uint64_t)row_block * W * slots;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_pack_shard, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st,
+                       (const uint32_t*)image, W, H, row_block, shard, count, slots, (uint32_t*)dst);
+    return hipGetLastError();
+}
+
+hipError_t launch_unpack_shards(const void* gathered, uint32_t W, uint32_t H, uint32_t row_block, uint32_t count,
+                                uint32_t slots, void* image, hipStream_t st)
+{
+    const uint64_t n = (uint64_t)W * H;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_unpack_shards, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st,
+                       (const uint32_t*)gathered, W, H, row_block, count, slots, (uint32_t*)image);
+    return hipGetLastError();
+}
+
+}  // namespace vrc

@@ -1,0 +1,214 @@
+// hip_raycaster.hpp -- C++ host adapter over the C ABI (include/vrc.h) that
+// presents the reference's operator interface for the hot path:
+//
+//   vrc_host::HipLSVO       <- LSVO<N> : Volumetric   (include/lsvo.hpp:10-33,
+//                              include/volumetric.hpp:55-61): castRay / setCell
+//   vrc_host::HipRayCaster  <- RayCaster (include/raycaster.hpp:43-283):
+//                              setLightPosition, renderRay's per-frame batch
+//                              (renderFrame), samples_to_image, resetSamples,
+//                              public flags use_gi / use_samples, render_image
+//
+// Header-only, C++14, no GLM / SFML needed.  When the reference's own headers
+// are on the include path, define VRC_WITH_REFERENCE_HEADERS before including
+// this file to also get `HipVolumetric`, a real `Volumetric` subclass that can
+// be handed to Camera::getClosestPoint and friends unchanged.
+#pragma once
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/vrc.h"
+
+namespace vrc_host {
+
+struct Vec3 { float x, y, z; };   // layout-compatible with glm::vec3
+struct Vec2 { float x, y; };
+
+// include/cell.hpp:3-24 -- every LSVO hit reports this one cell (lsvo.hpp:21-23)
+struct Cell {
+    enum Type { Empty, Solid, Mirror };
+    enum Texture { None, Grass, Red, White };
+    Type type = Solid;
+    Texture texture = Grass;
+};
+
+// include/volumetric.hpp:7-22
+struct HitPoint {
+    Vec3 position{0, 0, 0};
+    Vec3 normal{0, 0, 0};
+    Vec2 voxel_coord{0, 0};
+    const Cell* cell = nullptr;   // nullptr = miss
+    float distance = 0.0f;
+    uint32_t complexity = 0u;
+};
+
+inline void check(int rc, const char* what)
+{
+    if (rc != VRC_OK) throw std::runtime_error(std::string(what) + ": " + vrc_last_error());
+}
+
+// LSVO<N> (lsvo.hpp:10): immutable, device resident; castRay is const and may be
+// called from any number of threads, like the reference's (main.cpp:139-152).
+class HipLSVO {
+public:
+    // LSVO(const SVO<N>&) + compileSVO replaced by a pre-compiled LNode array
+    HipLSVO(const vrc_lnode* lnodes, uint64_t n_nodes, uint32_t depth, int device = 0)
+    {
+        check(vrc_scene_create(lnodes, n_nodes, depth, device, &scene_), "vrc_scene_create");
+    }
+    ~HipLSVO() { vrc_scene_destroy(scene_); }
+    HipLSVO(const HipLSVO&) = delete;
+    HipLSVO& operator=(const HipLSVO&) = delete;
+
+    // lsvo.hpp:26 -- a no-op in the reference too
+    void setCell(Cell::Type, Cell::Texture, uint32_t, uint32_t, uint32_t) {}
+
+    // lsvo.hpp:33
+    HitPoint castRay(const Vec3& position, Vec3 d, const float ray_size_coef = 0.0f, const float ray_size_bias = 0.0f) const
+    {
+        vrc_hit h;
+        const float o[3] = {position.x, position.y, position.z}, dir[3] = {d.x, d.y, d.z};
+        check(vrc_cast_ray(scene_, o, dir, ray_size_coef, ray_size_bias, &h), "vrc_cast_ray");
+        return convert(h);
+    }
+
+    // batch form: what a GPU-backed Volumetric needs to be useful
+    std::vector<HitPoint> castRays(const std::vector<Vec3>& positions, const std::vector<Vec3>& directions,
+                                   float ray_size_coef = 0.0f, float ray_size_bias = 0.0f) const
+    {
+        if (positions.size() != directions.size()) throw std::invalid_argument("castRays: size mismatch");
+        const uint64_t n = positions.size();
+        std::vector<vrc_hit> raw(n);
+        std::vector<float> coef(n, ray_size_coef), bias(n, ray_size_bias);
+        check(vrc_cast_rays(scene_, n, &positions[0].x, &directions[0].x, coef.data(), bias.data(), raw.data(),
+                            VRC_MEM_HOST, nullptr), "vrc_cast_rays");
+        std::vector<HitPoint> out(n);
+        for (uint64_t i = 0; i < n; ++i) out[i] = convert(raw[i]);
+        return out;
+    }
+
+    vrc_scene* handle() const { return scene_; }
+    uint32_t depth() const { return vrc_scene_depth(scene_); }
+    Cell cell;   // lsvo.hpp:289
+
+private:
+    HitPoint convert(const vrc_hit& h) const
+    {
+        HitPoint p;
+        p.position = {h.position[0], h.position[1], h.position[2]};
+        p.normal = {h.normal[0], h.normal[1], h.normal[2]};
+        p.voxel_coord = {h.voxel_coord[0], h.voxel_coord[1]};
+        p.cell = h.hit ? &cell : nullptr;
+        p.distance = h.distance;
+        p.complexity = h.complexity;
+        return p;
+    }
+    vrc_scene* scene_ = nullptr;
+};
+
+// Camera values Camera::getRay reads (camera_controller.hpp:16-49); the Camera /
+// FlyController classes themselves stay untouched on the host.
+struct CameraState {
+    Vec3 position{0, 0, 0};
+    Vec2 view_angle{0, 0};
+    float aperture = 0.0f, focal_length = 1.0f, fov = 1.0f;
+    vrc_camera to_abi() const
+    {
+        vrc_camera c;
+        c.position[0] = position.x; c.position[1] = position.y; c.position[2] = position.z;
+        vrc_make_rotation(view_angle.x, view_angle.y, c.rot);   // generateRotationMatrix, utils.cpp:94-100
+        c.fov = fov; c.aperture = aperture; c.focal_length = focal_length;
+        return c;
+    }
+};
+
+// RayCaster (raycaster.hpp:43-283).  render_image and the Sample accumulators
+// live in HBM; renderFrame replaces the swarm lambda of main.cpp:139-152.
+class HipRayCaster {
+public:
+    HipRayCaster(const HipLSVO& svo, uint32_t width, uint32_t height) : width_(width), height_(height)
+    {
+        check(vrc_renderer_create(svo.handle(), width, height, &r_), "vrc_renderer_create");
+    }
+    ~HipRayCaster() { vrc_renderer_destroy(r_); }
+    HipRayCaster(const HipRayCaster&) = delete;
+    HipRayCaster& operator=(const HipRayCaster&) = delete;
+
+    void setLightPosition(const Vec3& position) { light_ = position; }   // raycaster.hpp:62
+
+    // One frame: Camera::getRay + renderRay for every selected pixel (main.cpp:139-152).
+    // checker_board_offset = -1 renders every pixel; 0 / 1 as main.cpp:137,143.
+    void renderFrame(const CameraState& camera, int32_t checker_board_offset = -1, uint32_t spp = 1, void* stream = nullptr)
+    {
+        vrc_frame_params p{};
+        p.light_position[0] = light_.x; p.light_position[1] = light_.y; p.light_position[2] = light_.z;
+        p.use_gi = use_gi; p.use_samples = use_samples;
+        p.shadow_samples = 0; p.gi_bounces = 1;
+        p.checker_parity = checker_board_offset; p.spp = spp;
+        p.seed = seed; p.frame_index = frame_index_;
+        const vrc_camera c = camera.to_abi();
+        check(vrc_render_frame(r_, &c, &p, stream), "vrc_render_frame");
+        frame_index_ += spp;
+    }
+
+    void samples_to_image(void* stream = nullptr) { check(vrc_samples_to_image(r_, stream), "vrc_samples_to_image"); }   // raycaster.hpp:94
+    void resetSamples(void* stream = nullptr) { check(vrc_reset_samples(r_, stream), "vrc_reset_samples"); }            // raycaster.hpp:105
+
+    // render_image (raycaster.hpp:261) copied to host RGBA8, row-major
+    std::vector<uint8_t> render_image() const
+    {
+        std::vector<uint8_t> img((size_t)width_ * height_ * 4);
+        check(vrc_read_image(r_, img.data(), nullptr), "vrc_read_image");
+        return img;
+    }
+
+    vrc_frame_stats stats(bool reset = false)
+    {
+        vrc_frame_stats s;
+        check(vrc_get_stats(r_, &s, reset ? 1 : 0, nullptr), "vrc_get_stats");
+        return s;
+    }
+
+    bool use_gi = false;        // raycaster.hpp:274
+    bool use_samples = false;   // raycaster.hpp:275
+    uint32_t seed = 0x9E3779B9u;
+
+private:
+    vrc_renderer* r_ = nullptr;
+    uint32_t width_, height_;
+    uint32_t frame_index_ = 0;
+    Vec3 light_{0, 0, 0};
+};
+
+}  // namespace vrc_host
+
+#ifdef VRC_WITH_REFERENCE_HEADERS
+// Drop-in Volumetric (needs the reference's include/ and GLM on the include path).
+#include "volumetric.hpp"
+class HipVolumetric : public Volumetric {
+public:
+    HipVolumetric(const vrc_lnode* lnodes, uint64_t n_nodes, uint32_t depth, int device = 0) : impl_(lnodes, n_nodes, depth, device)
+    {
+        cell_.type = Cell::Solid; cell_.texture = Cell::Grass;
+    }
+    HitPoint castRay(const glm::vec3& position, glm::vec3 direction, const float coef, const float bias) const override
+    {
+        const vrc_host::HitPoint h = impl_.castRay({position.x, position.y, position.z}, {direction.x, direction.y, direction.z}, coef, bias);
+        HitPoint out;
+        out.position = glm::vec3(h.position.x, h.position.y, h.position.z);
+        out.normal = glm::vec3(h.normal.x, h.normal.y, h.normal.z);
+        out.voxel_coord = glm::vec2(h.voxel_coord.x, h.voxel_coord.y);
+        out.cell = h.cell ? &cell_ : nullptr;
+        out.distance = h.distance;
+        out.complexity = h.complexity;
+        return out;
+    }
+    void setCell(Cell::Type, Cell::Texture, uint32_t, uint32_t, uint32_t) override {}
+    const vrc_host::HipLSVO& impl() const { return impl_; }
+private:
+    vrc_host::HipLSVO impl_;
+    Cell cell_;
+};
+#endif

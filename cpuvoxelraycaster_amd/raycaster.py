@@ -1,0 +1,199 @@
+"""Thin Python mirror of the reference's operator interface for the hot path,
+over the C ABI (include/vrc.h).  Names follow the reference:
+
+  LSVO.castRay                 <- LSVO<N>::castRay          (include/lsvo.hpp:33)
+  RayCaster.setLightPosition   <- RayCaster::setLightPosition (include/raycaster.hpp:62)
+  RayCaster.renderFrame        <- the swarm lambda: getRay + renderRay per pixel (src/main.cpp:139-152)
+  RayCaster.samples_to_image   <- raycaster.hpp:94
+  RayCaster.resetSamples       <- raycaster.hpp:105
+
+All compute runs in the HIP kernels of libvrc_hip.so; numpy / torch are only
+used to hold buffers."""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import Camera, FrameParams, FrameStats, HIT_DTYPE, VrcError, check, ptr
+
+
+class LSVO:
+    """Device-resident linear sparse voxel octree (Volumetric implementation)."""
+
+    def __init__(self, lnodes, depth, device=0, textures=None):
+        L = capi.load()
+        lnodes = np.ascontiguousarray(lnodes)
+        if lnodes.dtype.itemsize != 8:
+            raise VrcError("lnodes must be an array of 8-byte LNode records")
+        self._h = C.c_void_p()
+        check(L.vrc_scene_create(ptr(lnodes), lnodes.shape[0], depth, device, C.byref(self._h)))
+        self.depth = depth
+        self.device = device
+        self.n_nodes = int(lnodes.shape[0])
+        if textures is not None:
+            self.setTextures(*textures)
+
+    def setTextures(self, top_rgb, side_rgb):
+        top = np.ascontiguousarray(top_rgb, dtype=np.uint8).reshape(-1)
+        side = np.ascontiguousarray(side_rgb, dtype=np.uint8).reshape(-1)
+        assert top.size == 768 and side.size == 768
+        check(capi.load().vrc_scene_set_textures(self._h, ptr(top), ptr(side)))
+
+    def castRay(self, position, direction, ray_size_coef=0.0, ray_size_bias=0.0):
+        """Single ray (Camera::getClosestPoint path); returns a HIT_DTYPE record."""
+        out = np.zeros(1, HIT_DTYPE)
+        o = np.ascontiguousarray(position, np.float32)
+        d = np.ascontiguousarray(direction, np.float32)
+        check(capi.load().vrc_cast_ray(self._h, ptr(o), ptr(d), ray_size_coef, ray_size_bias, ptr(out)))
+        return out[0]
+
+    def castRays(self, org, dir_, coef=None, bias=None):
+        """Batch form over host arrays."""
+        org = np.ascontiguousarray(org, np.float32).reshape(-1, 3)
+        dir_ = np.ascontiguousarray(dir_, np.float32).reshape(-1, 3)
+        n = org.shape[0]
+        if coef is not None:
+            coef = np.ascontiguousarray(np.broadcast_to(np.asarray(coef, np.float32), (n,)))
+        if bias is not None:
+            bias = np.ascontiguousarray(np.broadcast_to(np.asarray(bias, np.float32), (n,)))
+        out = np.zeros(n, HIT_DTYPE)
+        check(capi.load().vrc_cast_rays(self._h, n, ptr(org), ptr(dir_), ptr(coef), ptr(bias), ptr(out),
+                                        capi.VRC_MEM_HOST, None))
+        return out
+
+    def castRaysDevice(self, n, org_ptr, dir_ptr, out_ptr, coef_ptr=None, bias_ptr=None, stream=None):
+        """Batch form over device pointers (asynchronous on `stream`)."""
+        check(capi.load().vrc_cast_rays(self._h, n, ptr(org_ptr), ptr(dir_ptr), ptr(coef_ptr), ptr(bias_ptr),
+                                        ptr(out_ptr), capi.VRC_MEM_DEVICE, ptr(stream)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            capi.load().vrc_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Grid3D:
+    """Dense grid (grid_3d.hpp); cells[x, y, z] = Cell::Type (0 = Empty)."""
+
+    def __init__(self, cells, device=0):
+        cells = np.ascontiguousarray(cells, dtype=np.uint8)
+        X, Y, Z = cells.shape
+        self._h = C.c_void_p()
+        check(capi.load().vrc_grid_create(ptr(cells), X, Y, Z, device, C.byref(self._h)))
+
+    def castRays(self, org, dir_):
+        org = np.ascontiguousarray(org, np.float32).reshape(-1, 3)
+        dir_ = np.ascontiguousarray(dir_, np.float32).reshape(-1, 3)
+        out = np.zeros(org.shape[0], HIT_DTYPE)
+        check(capi.load().vrc_grid_cast_rays(self._h, org.shape[0], ptr(org), ptr(dir_), ptr(out),
+                                             capi.VRC_MEM_HOST, None))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            capi.load().vrc_grid_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def make_camera(position, rot, fov=1.0, aperture=0.0, focal_length=1.0):
+    cam = Camera()
+    cam.position[:] = [float(v) for v in position]
+    cam.rot[:] = [float(v) for v in rot]
+    cam.fov, cam.aperture, cam.focal_length = fov, aperture, focal_length
+    return cam
+
+
+class RayCaster:
+    """raycaster.hpp:43-283 with the framebuffer and sample accumulators on the GPU."""
+
+    def __init__(self, svo, render_size):
+        self.svo = svo
+        self.width, self.height = int(render_size[0]), int(render_size[1])
+        self._h = C.c_void_p()
+        check(capi.load().vrc_renderer_create(svo._h, self.width, self.height, C.byref(self._h)))
+        self.light_position = (0.0, 0.0, 0.0)
+        self.use_gi = False
+        self.use_samples = False
+        self.shadow_samples = 0      # 0 = reference default
+        self.gi_bounces = 1
+        self.seed = 0x9E3779B9
+        self.frame_index = 0
+
+    def setLightPosition(self, position):
+        self.light_position = tuple(float(v) for v in position)
+
+    def params(self, spp=1, checker_parity=-1, row_block=0, shard_index=0, shard_count=1):
+        p = FrameParams()
+        p.light_position[:] = self.light_position
+        p.use_gi, p.use_samples = int(self.use_gi), int(self.use_samples)
+        p.shadow_samples, p.gi_bounces = self.shadow_samples, self.gi_bounces
+        p.checker_parity, p.spp = checker_parity, spp
+        p.seed, p.frame_index = self.seed, self.frame_index
+        p.row_block, p.shard_index, p.shard_count = row_block, shard_index, shard_count
+        return p
+
+    def renderFrame(self, camera, spp=1, checker_parity=-1, stream=None, row_block=0, shard_index=0, shard_count=1):
+        p = self.params(spp, checker_parity, row_block, shard_index, shard_count)
+        check(capi.load().vrc_render_frame(self._h, C.byref(camera), C.byref(p), ptr(stream)))
+        self.frame_index += spp
+
+    def setPrimaryCapture(self, dev_ptr):
+        check(capi.load().vrc_renderer_set_primary_capture(self._h, ptr(dev_ptr)))
+
+    def samples_to_image(self, stream=None):
+        check(capi.load().vrc_samples_to_image(self._h, ptr(stream)))
+
+    def resetSamples(self, stream=None):
+        check(capi.load().vrc_reset_samples(self._h, ptr(stream)))
+
+    def clearImage(self, stream=None):
+        check(capi.load().vrc_clear_image(self._h, ptr(stream)))
+
+    def image_ptr(self):
+        return capi.load().vrc_image_device_ptr(self._h)
+
+    def readImage(self, stream=None):
+        img = np.zeros((self.height, self.width, 4), np.uint8)
+        check(capi.load().vrc_read_image(self._h, ptr(img), ptr(stream)))
+        return img
+
+    def writeImage(self, img, stream=None):
+        img = np.ascontiguousarray(img, np.uint8)
+        assert img.shape == (self.height, self.width, 4)
+        check(capi.load().vrc_write_image(self._h, ptr(img), ptr(stream)))
+
+    def readAccum(self, stream=None):
+        acc = np.zeros((self.height, self.width, 4), np.uint32)
+        check(capi.load().vrc_read_accum(self._h, ptr(acc), ptr(stream)))
+        return acc
+
+    def stats(self, reset=False, stream=None):
+        st = FrameStats()
+        check(capi.load().vrc_get_stats(self._h, C.byref(st), int(reset), ptr(stream)))
+        return st
+
+    def packShard(self, row_block, shard_index, shard_count, dst_ptr, stream=None):
+        check(capi.load().vrc_pack_shard(self._h, row_block, shard_index, shard_count, ptr(dst_ptr), ptr(stream)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            capi.load().vrc_renderer_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

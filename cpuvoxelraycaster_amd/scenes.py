@@ -1,0 +1,37 @@
+"""Synthetic inputs of the benchmark configurations:
+the reference's terrain scene (src/main.cpp:59-76), camera (main.cpp:50-53)
+and light (main.cpp:124-126), scaled by S/512 for other scene sizes."""
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def load_terrain_heights():
+    """int32 height[x, z] of main.cpp:69 for x, z < 1024 (fixture generated from
+    the reference's vendored FastNoise by tools/make_golden.py)."""
+    return np.load(os.path.join(GOLDEN, "terrain_height_1024.npz"))["height"].astype(np.int32)
+
+
+def load_textures():
+    """(top, side) 16x16 RGB tables of res/grass_{top,side}_16x16.bmp."""
+    top = np.fromfile(os.path.join(GOLDEN, "grass_top_16x16.rgb"), np.uint8)
+    side = np.fromfile(os.path.join(GOLDEN, "grass_side_16x16.rgb"), np.uint8)
+    return top, side
+
+
+def reference_light(depth):
+    """setLightPosition argument of main.cpp:124-126 for a 2^depth scene (SVO space)."""
+    size = np.float32(1 << depth)
+    world = np.array([-200.0, -1000.0, -300.0], np.float32) * np.float32(size / np.float32(512.0))
+    return world * (np.float32(1.0) / size) + np.float32(1.0)
+
+
+def reference_camera(depth, pitch=-0.5, yaw=0.0, aperture=0.0, focal_length=1.0, make_rotation=None):
+    """Camera of main.cpp:50-53 at (S/2, 200*S/512, S/2), fov 1."""
+    from . import capi, raycaster
+    s = float(1 << depth)
+    rot = (make_rotation or capi.make_rotation)(yaw, pitch)
+    return raycaster.make_camera((s / 2, 200.0 * s / 512.0, s / 2), rot, 1.0, aperture, focal_length)

@@ -1,0 +1,206 @@
+/*
+ * vrc.h -- C ABI of the MI355X-native voxel ray-traversal hot path
+ * (drop-in for the per-ray / per-frame operators of johnBuffer/CpuVoxelRaycaster).
+ *
+ * Plain pointers and sizes only.  All citations are file:line under the
+ * reference tree.  The library is libvrc_hip.so (cpuvoxelraycaster_amd/csrc);
+ * every compute entry point runs hand-written HIP kernels for gfx950 and fails
+ * with VRC_ERR_NO_DEVICE when no GPU is present -- there is no CPU fallback.
+ *
+ * Error convention (the reference has none to inherit: volumetric.hpp:55-61
+ * has no error channel): every function returns 0 on success or a negative
+ * VRC_ERR_* code; vrc_last_error() returns a thread-local message.
+ *
+ * Threading: a vrc_scene is immutable after creation and may be shared by
+ * any number of renderers / threads (the reference calls castRay concurrently
+ * from 16 workers, main.cpp:139-152).  A vrc_renderer is not re-entrant.
+ *
+ * Streams: `stream` arguments are hipStream_t handles passed as void*
+ * (NULL = the default stream).  Calls taking a stream are asynchronous on it
+ * unless stated otherwise.
+ */
+#ifndef VRC_H
+#define VRC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VRC_OK                0
+#define VRC_ERR_INVALID      -1   /* bad argument */
+#define VRC_ERR_NO_DEVICE    -2   /* no HIP device / HIP runtime error at init */
+#define VRC_ERR_HIP          -3   /* HIP runtime call failed (see vrc_last_error) */
+#define VRC_ERR_OOM          -4
+
+#define VRC_MEM_HOST   0
+#define VRC_MEM_DEVICE 1
+
+#define VRC_MAX_DEPTH 11          /* the loop bound of lsvo.hpp:72 binds from depth 12 on */
+
+/* include/lsvo_utils.hpp:5-18 -- the 8-byte linear octree node the kernels
+ * consume: index 0 = root; a non-empty internal node i owns the 8 consecutive
+ * slots starting at i + child_offset, slot k = child (x=k&1, y=k>>1&1, z=k>>2)
+ * (src/lsvo_utils.cpp:29-47). */
+typedef struct vrc_lnode {
+    uint8_t color;
+    uint8_t child_mask;
+    uint8_t leaf_mask;
+    uint8_t pad;
+    uint32_t child_offset;
+} vrc_lnode;
+
+/* include/volumetric.hpp:7-22 (HitPoint, 48 bytes).  `const Cell* cell` is
+ * replaced by `hit` + `node`: hit = kind | child_shift<<8 | scale<<16 with
+ * kind 0 = miss (cell == nullptr), 1 = unit-voxel leaf (lsvo.hpp:92-95),
+ * 2 = LOD cut-off (lsvo.hpp:82-85); node = index of the LNode whose child was
+ * hit.  The cell is always {Solid, Grass} (lsvo.hpp:21-23).  On a miss all
+ * other fields except `complexity` are zero (uninitialised in the reference). */
+typedef struct vrc_hit {
+    float position[3];
+    float normal[3];        /* (+-1,0,0) (0,+-2,0) (0,0,+-4), lsvo.hpp:149 */
+    float voxel_coord[2];
+    uint32_t hit;
+    uint32_t node;
+    float distance;
+    uint32_t complexity;    /* loop iterations, lsvo.hpp:73 */
+} vrc_hit;
+
+typedef struct vrc_scene vrc_scene;        /* device-resident LSVO + albedo tables */
+typedef struct vrc_grid vrc_grid;          /* device-resident dense Grid3D */
+typedef struct vrc_renderer vrc_renderer;  /* RayCaster state: framebuffer + sample accumulators */
+
+const char *vrc_last_error(void);
+int vrc_device_count(void);                /* >= 0, or VRC_ERR_NO_DEVICE */
+
+/* ---- scene: LSVO<N> (lsvo.hpp:12-24) ---------------------------------- */
+
+/* Copies `n_nodes` LNodes (host memory) to `device` and keeps them resident.
+ * Replaces LSVO(const SVO<N>&) + compileSVO for a pre-compiled array. */
+int vrc_scene_create(const vrc_lnode *lnodes, uint64_t n_nodes, uint32_t depth,
+                     int device, vrc_scene **out);
+/* 16x16 RGB tables, top-down rows, as sf::Image::getPixel sees
+ * res/grass_{top,side}_16x16.bmp (raycaster.hpp:53-54). */
+int vrc_scene_set_textures(vrc_scene *s, const uint8_t top_rgb[768], const uint8_t side_rgb[768]);
+int vrc_scene_destroy(vrc_scene *s);
+uint64_t vrc_scene_node_count(const vrc_scene *s);
+uint32_t vrc_scene_depth(const vrc_scene *s);
+
+/* Scene construction that precedes the path (main.cpp:59-88):
+ * builds the exact compileSVO layout (lsvo_utils.cpp:4-49) for the terrain
+ * generator of main.cpp:63-76 from height[x*size+z] (the int32 `height` of
+ * main.cpp:69), without a pointer tree.  Host code.  *out is released with
+ * vrc_free_host. */
+int vrc_build_terrain_lsvo(const int32_t *height, uint32_t depth,
+                           vrc_lnode **out, uint64_t *n_nodes);
+/* Same layout for an arbitrary occupancy volume: solid[(x*size+y)*size+z] != 0. */
+int vrc_build_volume_lsvo(const uint8_t *solid, uint32_t depth,
+                          vrc_lnode **out, uint64_t *n_nodes);
+void vrc_free_host(void *p);
+
+/* ---- per-ray operator: Volumetric::castRay (volumetric.hpp:58, lsvo.hpp:33) */
+
+/* Batch form of HitPoint castRay(position, direction, ray_size_coef,
+ * ray_size_bias).  org_xyz / dir_xyz: n x 3 floats; coef / bias: n floats or
+ * NULL (= 0).  `mem` says where ALL ray and output buffers live
+ * (VRC_MEM_HOST: staged through the library; VRC_MEM_DEVICE: used in place,
+ * asynchronous on `stream`). */
+int vrc_cast_rays(const vrc_scene *s, uint64_t n,
+                  const float *org_xyz, const float *dir_xyz,
+                  const float *coef, const float *bias,
+                  vrc_hit *out, int mem, void *stream);
+
+/* Single-ray form for Camera::getClosestPoint (camera_controller.hpp:56-60). Synchronous. */
+int vrc_cast_ray(const vrc_scene *s, const float org[3], const float dir[3],
+                 float ray_size_coef, float ray_size_bias, vrc_hit *out);
+
+/* ---- dense grid: Grid3D<X,Y,Z> (grid_3d.hpp:10-138) ------------------- */
+
+/* cells[(x*Y + y)*Z + z] = Cell::Type (0 = Empty). */
+int vrc_grid_create(const uint8_t *cells, int32_t X, int32_t Y, int32_t Z, int device, vrc_grid **out);
+int vrc_grid_destroy(vrc_grid *g);
+/* Grid3D::castRay(position, direction) (grid_3d.hpp:36-132), voxel units. */
+int vrc_grid_cast_rays(const vrc_grid *g, uint64_t n, const float *org_xyz, const float *dir_xyz,
+                       vrc_hit *out, int mem, void *stream);
+
+/* ---- per-frame operator: RayCaster (raycaster.hpp:43-283) ------------- */
+
+/* Camera (camera_controller.hpp:16-61).  The Camera class itself stays on the
+ * host; these are the values Camera::getRay reads. */
+typedef struct vrc_camera {
+    float position[3];      /* world voxel units */
+    float rot[9];           /* glm::mat3 rot_mat, columns m[0], m[1], m[2] */
+    float fov;
+    float aperture;
+    float focal_length;
+} vrc_camera;
+
+typedef struct vrc_frame_params {
+    float light_position[3];  /* RayCaster::setLightPosition (raycaster.hpp:62), SVO space */
+    uint32_t use_gi;          /* raycaster.hpp:274 */
+    uint32_t use_samples;     /* raycaster.hpp:275 */
+    uint32_t shadow_samples;  /* 0 = reference default: use_samples ? 4 : 1 (raycaster.hpp:147) */
+    uint32_t gi_bounces;      /* 0/1 = reference (one indirect bounce); 2 = extension */
+    int32_t checker_parity;   /* -1 = every pixel; 0/1 = checker_board_offset (main.cpp:137,143) */
+    uint32_t spp;             /* renderRay-equivalents per pixel in this call (>= 1) */
+    uint32_t seed;            /* counter-based RNG key ... */
+    uint32_t frame_index;     /* ... sample s of this call uses frame_index + s */
+    uint32_t row_block;       /* multi-GPU: rows per shard block (0 = whole frame) */
+    uint32_t shard_index;     /* this renderer renders row blocks b with b % shard_count == shard_index */
+    uint32_t shard_count;
+} vrc_frame_params;
+
+typedef struct vrc_frame_stats {
+    uint64_t rays;            /* LSVO::castRay-equivalent traversals executed */
+    uint64_t sum_complexity;  /* sum of HitPoint::complexity over them (8 B each = algorithmic bytes) */
+    uint64_t primary_hits;
+    uint64_t pixels;          /* pixel-samples shaded */
+} vrc_frame_stats;
+
+/* RayCaster(svo, render_size) (raycaster.hpp:48-60): framebuffer cleared to
+ * opaque black (sf::Image::create), accumulators zero. */
+int vrc_renderer_create(const vrc_scene *s, uint32_t width, uint32_t height, vrc_renderer **out);
+int vrc_renderer_destroy(vrc_renderer *r);
+
+/* One frame = what the swarm lambda does (main.cpp:139-152): for every selected
+ * pixel, Camera::getRay + RayCaster::renderRay, `spp` times.  Adds to the
+ * renderer's running vrc_frame_stats.  Asynchronous on `stream`. */
+int vrc_render_frame(vrc_renderer *r, const vrc_camera *cam, const vrc_frame_params *p, void *stream);
+/* Optional: also record the primary-ray HitPoint of sample 0 per pixel into
+ * prim_dev (device memory, width*height vrc_hit) during the next frames; NULL disables. */
+int vrc_renderer_set_primary_capture(vrc_renderer *r, vrc_hit *prim_dev);
+
+int vrc_samples_to_image(vrc_renderer *r, void *stream);  /* raycaster.hpp:94-103 */
+int vrc_reset_samples(vrc_renderer *r, void *stream);     /* raycaster.hpp:105-116 */
+int vrc_clear_image(vrc_renderer *r, void *stream);       /* render_image.create() again */
+
+/* render_image (raycaster.hpp:261): RGBA8 row-major, width*height*4 bytes. */
+void *vrc_image_device_ptr(vrc_renderer *r);              /* for device-side gathers (RCCL) */
+void *vrc_accum_device_ptr(vrc_renderer *r);              /* uint32 r,g,b,count per pixel */
+int vrc_read_image(vrc_renderer *r, uint8_t *rgba_host, void *stream);   /* synchronous */
+int vrc_write_image(vrc_renderer *r, const uint8_t *rgba_host, void *stream); /* synchronous */
+int vrc_read_accum(vrc_renderer *r, uint32_t *accum_host, void *stream);  /* synchronous */
+
+/* Synchronises `stream`, returns and optionally clears the running stats. */
+int vrc_get_stats(vrc_renderer *r, vrc_frame_stats *out, int reset, void *stream);
+
+/* Multi-GPU frame sharding: compact this shard's row blocks into
+ * `dst_dev` (ceil(nblocks/shard_count) blocks of row_block*width*4 bytes), and
+ * the inverse scatter of an all-gathered buffer [shard][slot] into a full frame. */
+uint64_t vrc_shard_bytes(uint32_t width, uint32_t height, uint32_t row_block, uint32_t shard_count);
+int vrc_pack_shard(vrc_renderer *r, uint32_t row_block, uint32_t shard_index, uint32_t shard_count,
+                   void *dst_dev, void *stream);
+int vrc_unpack_shards(const void *gathered_dev, uint32_t width, uint32_t height, uint32_t row_block,
+                      uint32_t shard_count, void *image_dev, void *stream);
+
+/* Host helper: generateRotationMatrix (utils.cpp:94-100) for Camera::setViewAngle. */
+void vrc_make_rotation(float angle_x, float angle_y, float rot[9]);
+
+/* Kernel tuning knobs (persistent-threads geometry); 0 = default. */
+int vrc_set_tuning(uint32_t blocks_per_cu, uint32_t refill_threshold, uint32_t chunk);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -103,6 +103,10 @@ void orc_svo_set_cell(orc_svo *s, uint32_t x, uint32_t y, uint32_t z)
 {
     uint32_t size = 1u << s->depth;
     uint32_t node = 1;
+    /* out-of-volume coordinates index Node::sub out of bounds in the reference
+     * (UB; happens for the terrain generator at S <= 128 where y + S/2 >= S):
+     * dropped here. */
+    if (x >= size || y >= size || z >= size) return;
     while (size != 1) {
         const uint32_t sub_size = size / 2;
         const uint32_t cx = x / sub_size, cy = y / sub_size, cz = z / sub_size;

@@ -1,0 +1,124 @@
+"""Pins the CPU oracle against what is known about the unmodified reference:
+the statistics SURVEY.md App. B / section 6 measured by running it (node counts,
+first nodes, level histogram, per-pose hit counts, loop-iteration statistics,
+normal-axis split, one sample hit).  The reference holds no tests or golden
+vectors of its own."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+
+@pytest.fixture(scope="module")
+def nodes9(heights):
+    return O.compile_terrain(9, heights)
+
+
+def test_terrain_fixture_range(heights):
+    h = heights[:512, :512]
+    assert (h.min(), h.max()) == (-17, 80)          # SURVEY App. B "raw noise heights -17..80"
+    top = np.maximum(16, np.minimum(512, h))
+    assert int((top - 1).sum()) == 8583552          # solid voxels at 512^3
+
+
+def test_lsvo_512_layout(nodes9):
+    n = nodes9
+    assert len(n) == 10528393 and len(n) * 8 == 84227144
+    assert int((n["child_mask"] != 0).sum()) == 1316049
+    assert int(n["child_offset"].max()) == 7883537
+    first = [(int(a["child_mask"]), int(a["leaf_mask"]), int(a["child_offset"])) for a in n[:5]]
+    assert first == [(204, 0, 1), (0, 0, 0), (0, 0, 0), (51, 0, 6), (51, 0, 5283557)]
+    assert np.all(n["color"] == 1)
+    # level histogram of non-empty internal nodes
+    level = np.zeros(len(n), np.int8)
+    counts = []
+    frontier = np.array([0], np.int64)
+    for lv in range(9):
+        counts.append(len(frontier))
+        nd = n[frontier]
+        nxt = []
+        for k in range(8):
+            sel = ((nd["child_mask"] >> k) & 1).astype(bool) & ~((nd["leaf_mask"] >> k) & 1).astype(bool)
+            nxt.append(frontier[sel] + nd["child_offset"][sel].astype(np.int64) + k)
+        frontier = np.concatenate(nxt)
+    assert counts == [1, 4, 16, 94, 537, 3220, 21166, 151272, 1139739]
+
+
+def test_lsvo_other_depths(heights):
+    assert len(O.compile_terrain(8, heights)) == 2646233        # 20.19 MiB
+
+
+def _frame(nodes9, textures, pitch):
+    top, side = textures
+    W, H = 960, 540
+    light = np.array([-200, -1000, -300], np.float32) * np.float32(1 / 512) + np.float32(1)
+    cam = O.make_camera((256, 200, 256), O.make_rotation(0.0, pitch), 1.0, 0.0, 1.0)  # Camera defaults
+    p = O.make_params(W, H, light, use_gi=0, use_samples=1, shadow_samples=1)
+    _, _, prim, st = O.render_frame(nodes9, 9, top, side, cam, p, want_prim=True, threads=8)
+    return prim, st
+
+
+def test_primary_rays_pitch_m05(nodes9, textures):
+    prim, _ = _frame(nodes9, textures, -0.5)
+    c = prim["complexity"]
+    hit = prim["hit"] != 0
+    assert int(hit.sum()) == 514400
+    assert round(float(c.mean()), 2) == 38.39
+    assert [int(np.percentile(c, q)) for q in (50, 90, 99)] == [35, 59, 87]
+    assert int(c.max()) == 147
+    n = prim["normal"][hit]
+    nx = n[:, 0] != 0
+    ny = ~nx & (n[:, 1] != 0)
+    nz = ~nx & ~ny & (n[:, 2] != 0)
+    assert (int(nx.sum()), int(ny.sum()), int(nz.sum())) == (100924, 225631, 187845)
+    assert int(((n != 0).sum(1) > 1).sum()) == 10           # multi-axis normals
+    # sample hit at lens (0, 0.2) = pixel (480, 378)
+    h = prim[378 * 960 + 480]
+    assert np.allclose(h["position"], [1.5, 1.46875, 1.59325], atol=2e-6)
+    assert h["normal"].tolist() == [-0.0, -2.0, -0.0] and np.signbit(h["normal"]).all()
+    assert abs(float(h["distance"]) - 0.121648) < 1e-6 and int(h["complexity"]) == 31
+
+
+def test_primary_rays_other_poses(nodes9, textures):
+    prim, _ = _frame(nodes9, textures, 0.0)
+    c = prim["complexity"]
+    assert int((prim["hit"] != 0).sum()) == 263162
+    assert round(float(c.mean()), 2) == 32.33 and int(c.max()) == 147
+    n = prim["normal"][prim["hit"] != 0]
+    assert int(((n != 0).sum(1) > 1).sum()) == 1389
+    prim, _ = _frame(nodes9, textures, -1.2)
+    c = prim["complexity"]
+    assert int((prim["hit"] != 0).sum()) == 518400
+    assert round(float(c.mean()), 2) == 24.37 and int(c.max()) == 106
+
+
+def test_misses_are_zeroed(nodes9):
+    org = np.array([[1.5, 1.1, 1.5]], np.float32)
+    d = np.array([[0.0, -1.0, 0.0]], np.float32)     # straight up into the sky
+    h = O.cast_rays(nodes9, 9, org, d)[0]
+    assert h["hit"] == 0 and h["complexity"] > 0
+    assert not h["position"].any() and not h["normal"].any() and h["distance"] == 0
+
+
+def test_rng_quantisation():
+    L = O.lib()
+    vals = {L.orc_get_rand_counter(k, -0.5, 0.5) for k in range(1000)}
+    assert len(vals) == 100                           # utils.cpp:77-81: 100 levels
+    assert min(vals) == -0.5 and max(vals) < 0.5
+    # xorshf96 first outputs (LP64 unsigned long)
+    L.orc_xorshf96_reset()
+    a = [L.orc_xorshf96() for _ in range(3)]
+    x, y, z = 123456789, 362436069, 521288629
+    exp = []
+    M = (1 << 64) - 1
+    for _ in range(3):
+        x ^= (x << 16) & M; x ^= x >> 5; x ^= (x << 1) & M
+        t = x; x = y; y = z; z = t ^ x ^ y
+        exp.append(z)
+    assert a == exp
+
+
+def test_frac_matches_modf():
+    L = O.lib()
+    for v in (0.0, 0.25, 513.75, 1023.999, -2.5, -0.0, 7.0):
+        assert L.orc_frac(v) == np.float32(np.modf(np.float32(v))[0])
