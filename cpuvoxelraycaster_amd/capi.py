@@ -91,6 +91,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    try:
+        # PyTorch bundles its own libamdhip64; it must be the HIP runtime of the
+        # process (loading /opt/rocm's first makes torch see "No HIP GPUs").
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise VrcError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(the HIP library is the product; there is no fallback)")

@@ -57,6 +57,7 @@ struct vrc_grid {
 
 struct vrc_renderer {
     const vrc_scene* scene;
+    int device;
     uint32_t width, height;
     void* d_image;  // RGBA8
     void* d_accum;  // 4 x u32 per pixel
@@ -272,7 +273,7 @@ extern "C" int vrc_renderer_create(const vrc_scene* s, uint32_t width, uint32_t 
     HIP_TRY(hipSetDevice(s->device));
     vrc_renderer* r = (vrc_renderer*)calloc(1, sizeof(vrc_renderer));
     if (!r) return fail(VRC_ERR_OOM, "out of host memory");
-    r->scene = s; r->width = width; r->height = height;
+    r->scene = s; r->device = s->device; r->width = width; r->height = height;
     const uint64_t n = (uint64_t)width * height;
     hipError_t e = hipMalloc(&r->d_image, n * 4);
     if (e == hipSuccess) e = hipMalloc(&r->d_accum, n * 16);
@@ -295,7 +296,7 @@ extern "C" int vrc_renderer_create(const vrc_scene* s, uint32_t width, uint32_t 
 extern "C" int vrc_renderer_destroy(vrc_renderer* r)
 {
     if (!r) return VRC_OK;
-    (void)hipSetDevice(r->scene->device);
+    (void)hipSetDevice(r->device);   // the scene may already be gone
     (void)hipFree(r->d_image);
     (void)hipFree(r->d_accum);
     (void)hipFree(r->d_stats);

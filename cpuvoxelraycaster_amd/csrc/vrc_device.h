@@ -54,6 +54,9 @@ __device__ __forceinline__ float get_rand(uint32_t k, float mn, float mx)
 }
 
 constexpr int SVO_MAX = 23;  // lsvo.hpp:37
+// Safety net (same constant as the oracle): no finite ray needs anywhere near
+// this many loop iterations; guarantees the kernels terminate.
+constexpr uint32_t MAX_ITERATIONS = 65536u;
 
 // Traversal state of one ray (one lane).  LSVO<N>::castRay, lsvo.hpp:33-172.
 struct Ray {
@@ -73,9 +76,17 @@ struct Ray {
     uint2 nd;                 // raw_data[parent_id], reloaded only when parent_id changes
 };
 
+__device__ __forceinline__ bool finite3(float x, float y, float z)
+{
+    // |v| < inf is false for NaN and +-inf
+    return (fabsf(x) < __builtin_inff()) && (fabsf(y) < __builtin_inff()) && (fabsf(z) < __builtin_inff());
+}
+
 // lsvo.hpp:36-70.  (dx,dy,dz) is conditioned in place (:44-46).  Returns
-// whether the loop condition of :72 holds (always true: scale = 22).
-__device__ __forceinline__ void ray_setup(Ray& r, const uint2* __restrict__ nodes,
+// whether the walk may start: false for non-finite input, for which the
+// reference's loop never terminates (no comparison at :116-118 holds) -- defined
+// as an immediate miss with complexity 0, in the oracle too.
+__device__ __forceinline__ bool ray_setup(Ray& r, const uint2* __restrict__ nodes,
                                           float ox, float oy, float oz, float& dx, float& dy, float& dz)
 {
     const float EPS = 1.0f / (float)(1 << SVO_MAX);
@@ -106,6 +117,7 @@ __device__ __forceinline__ void ray_setup(Ray& r, const uint2* __restrict__ node
     r.kind = 0u;
     r.shift = 0u;
     r.nd = nodes[0];
+    return finite3(ox, oy, oz) && finite3(dx, dy, dz);
 }
 
 // One iteration of the while loop at lsvo.hpp:72-146.  `stk` points at this
@@ -116,6 +128,7 @@ __device__ __forceinline__ bool ray_step(Ray& r, const uint2* __restrict__ nodes
                                          int depth, float coef, float bias)
 {
     const int depth_off = SVO_MAX - depth;
+    if (r.complexity >= MAX_ITERATIONS) return false;
     ++r.complexity;                                                     // :73
     const uint2 nd = r.nd;                                              // :74
     const float cx = r.px * r.tcx - r.tox;                              // :76

@@ -38,10 +38,9 @@ k_cast_rays(const uint2* __restrict__ nodes, int depth, uint64_t n,
     const float coef = coef_a ? coef_a[i] : 0.0f;
     const float bias = bias_a ? bias_a[i] : 0.0f;
     Ray r;
-    ray_setup(r, nodes, ox, oy, oz, dx, dy, dz);
+    bool active = ray_setup(r, nodes, ox, oy, oz, dx, dy, dz);
     uint2* stk = lds_stack + threadIdx.x;
     const int stride = blockDim.x;
-    bool active = true;
     while (active) active = ray_step(r, nodes, stk, stride, depth, coef, bias);
     Hit h;
     ray_finish(r, depth, ox, oy, oz, dx, dy, dz, h);
@@ -426,10 +425,7 @@ k_render(const FrameArgs a)
             stage = ST_PRIMARY;
             launch = true;
         }
-        if (launch) {
-            ray_setup(r, nodes, ox, oy, oz, dx, dy, dz);
-            active = true;
-        }
+        if (launch) active = ray_setup(r, nodes, ox, oy, oz, dx, dy, dz);
         if (__ballot(stage != ST_DONE) == 0ull) break;
     }
 

@@ -29,9 +29,21 @@ def reference_light(depth):
     return world * (np.float32(1.0) / size) + np.float32(1.0)
 
 
+def reference_camera_position(depth):
+    """Camera of main.cpp:50-53: (256, 200, 256) at 512^3, i.e. 56 voxels off the
+    mid-plane y = S/2.  The terrain's thickness (16..89 voxels) does not scale
+    with S, and the traversal sees the scene point-reflected (slot = idx ^
+    mirror_mask, lsvo.hpp:79), so the solid band is y in [S/2 - lim, S/2 - 2]: the
+    BASELINE rule 200*S/512 puts the camera INSIDE it for S < 512 (every primary
+    ray then "hits" at t = 0 with an all-zero normal).  Keep the 56-voxel
+    clearance for S <= 512 and the scaled height (free space) above."""
+    s = 1 << depth
+    y = s / 2 - 56.0 * max(1.0, s / 512.0)
+    return (s / 2.0, max(y, 4.0), s / 2.0)
+
+
 def reference_camera(depth, pitch=-0.5, yaw=0.0, aperture=0.0, focal_length=1.0, make_rotation=None):
-    """Camera of main.cpp:50-53 at (S/2, 200*S/512, S/2), fov 1."""
+    """Camera of main.cpp:50-53 (see reference_camera_position), fov 1."""
     from . import capi, raycaster
-    s = float(1 << depth)
     rot = (make_rotation or capi.make_rotation)(yaw, pitch)
-    return raycaster.make_camera((s / 2, 200.0 * s / 512.0, s / 2), rot, 1.0, aperture, focal_length)
+    return raycaster.make_camera(reference_camera_position(depth), rot, 1.0, aperture, focal_length)

@@ -196,6 +196,7 @@ uint64_t orc_svo_compile(const orc_svo *s, orc_lnode **out)
 /* ------------------------------------------------------------------------- */
 
 #define ORC_MAX_DEPTH 16
+#define ORC_MAX_ITERATIONS 65536u
 
 void orc_cast_ray(const orc_lnode *raw_data, uint32_t depth,
                   const float org[3], const float dir[3],
@@ -215,6 +216,13 @@ void orc_cast_ray(const orc_lnode *raw_data, uint32_t depth,
 
     const float px = org[0], py = org[1], pz = org[2];
     float dx = dir[0], dy = dir[1], dz = dir[2];
+    /* Non-finite input: with a NaN component no comparison at :116-118 holds, the
+     * walk makes no progress and the reference never returns.  Defined here (and
+     * in the HIP kernels) as an immediate miss with complexity 0.  This is what
+     * RayCaster reaches when a ray starts inside a solid voxel: the hit normal
+     * is all zero (App. A.10) and normalize() of the GI direction is NaN. */
+    if (!isfinite(px) || !isfinite(py) || !isfinite(pz) || !isfinite(dx) || !isfinite(dy) || !isfinite(dz))
+        return;
     /* :44-46 */
     if (fabsf(dx) < EPS) dx = copysignf(EPS, dx);
     if (fabsf(dy) < EPS) dy = copysignf(EPS, dy);
@@ -248,6 +256,9 @@ void orc_cast_ray(const orc_lnode *raw_data, uint32_t depth,
 
     /* :72 */
     while (scale < SVO_MAX_DEPTH && scale > MAX_DEPTH) {
+        /* safety net shared with the HIP kernels: no finite ray needs anywhere
+         * near this many iterations (max observed ~150 at 512^3) */
+        if (result->complexity >= ORC_MAX_ITERATIONS) break;
         ++result->complexity;                                 /* :73 */
         const orc_lnode parent_ref = raw_data[parent_id];     /* :74 */
         /* :76-77 */

@@ -125,3 +125,19 @@ def test_full_size_properties(terrain):
     # checksum against the oracle on a strided sample of the same rays
     sl = slice(0, None, 37)
     assert_hits_equal(got[sl], O.cast_rays(nodes, 9, org[sl], d[sl], threads=8))
+
+
+def test_non_finite_rays_terminate_as_misses(terrain):
+    """NaN / inf input never returns in the reference (no comparison holds, the walk
+    makes no progress); defined as an immediate miss in oracle and kernel alike."""
+    nodes, svo = terrain[9]
+    org, d = raygen.mixed_rays(4096, seed=11)
+    d[::7, 0] = np.nan
+    d[1::7, 2] = np.inf
+    org[2::7, 1] = np.nan
+    org[3::7, 0] = -np.inf
+    got = svo.castRays(org, d)
+    ref = O.cast_rays(nodes, 9, org, d)
+    assert_hits_equal(got, ref)
+    bad = ~(np.isfinite(org).all(1) & np.isfinite(d).all(1))
+    assert not got["hit"][bad].any() and not got["complexity"][bad].any()

@@ -122,3 +122,22 @@ def test_frac_matches_modf():
     L = O.lib()
     for v in (0.0, 0.25, 513.75, 1023.999, -2.5, -0.0, 7.0):
         assert L.orc_frac(v) == np.float32(np.modf(np.float32(v))[0])
+
+
+def test_scene_cameras_are_in_free_space(heights, textures):
+    """The benchmark cameras (scenes.reference_camera_position) must not sit inside
+    solid voxels: every primary hit has a non-zero normal."""
+    import cpuvoxelraycaster_amd as vrc
+    top, side = textures
+    for depth in (7, 8):
+        nodes = O.compile_terrain(depth, heights)
+        cam = O.make_camera(vrc.reference_camera_position(depth), O.make_rotation(0.0, -0.5))
+        p = O.make_params(96, 54, vrc.reference_light(depth), use_samples=1, shadow_samples=1)
+        _, _, prim, _ = O.render_frame(nodes, depth, top, side, cam, p, want_prim=True, threads=4)
+        hit = prim["hit"] != 0
+        assert hit.sum() > 1000 and (np.abs(prim["normal"][hit]).sum(1) > 0).all()
+
+
+def test_nan_ray_is_a_miss(nodes9):
+    h = O.cast_rays(nodes9, 9, np.array([[1.5, 1.4, 1.5]], np.float32), np.array([[np.nan, 0.5, 0.5]], np.float32))[0]
+    assert h["hit"] == 0 and h["complexity"] == 0
