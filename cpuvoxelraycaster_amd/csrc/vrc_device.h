@@ -17,8 +17,13 @@ __device__ __forceinline__ float smax(float a, float b) { return (a < b) ? b : a
 __device__ __forceinline__ float smin(float a, float b) { return (b < a) ? b : a; }  // std::min(a,b)
 __device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }       // utils.cpp:109-112
 __device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }       // utils.cpp:115-118
-// utils.cpp:60-64 std::modf fractional part: f - trunc(f) is exact; copysign keeps modf's -0.
-__device__ __forceinline__ float fracf_(float f) { return copysignf(f - truncf(f), f); }
+// utils.cpp:60-64 std::modf fractional part: f - trunc(f) is exact; copysign keeps
+// modf's -0; modf(+-inf) = +-0 (inf - inf would be NaN).
+__device__ __forceinline__ float fracf_(float f)
+{
+    const float r = (fabsf(f) == __builtin_inff()) ? 0.0f : f - truncf(f);
+    return copysignf(r, f);
+}
 // glm::dot / glm::normalize (stock scalar GLM)
 __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz)
 {
