@@ -79,7 +79,7 @@ def main():
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--pitch", type=float, default=-0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--tuning", default="", help="blocks_per_cu,refill_threshold,chunk")
+    ap.add_argument("--tuning", default="", help="blocks_per_cu,refill_threshold")
     args = ap.parse_args()
 
     import numpy as np

@@ -178,9 +178,7 @@ k_render(const FrameArgs a)
     const uint32_t spp = a.p.spp ? a.p.spp : 1u;
     const uint32_t tiles_per_row = (W + 7u) / 8u;
 
-    // wave-uniform work chunk [cur, end)
-    uint32_t cur = 0u, end = 0u;
-    bool exhausted = false;
+    bool exhausted = false;   // wave-uniform: the work queue has run dry
 
     // per-lane pixel program state
     uint32_t stage = ST_NEED_WORK;
@@ -354,25 +352,23 @@ k_render(const FrameArgs a)
         }
 
         // ------------------------------------------------------------------
-        // refill: lanes without a pixel take consecutive work items
+        // refill: the lanes without a pixel take consecutive work items -- one
+        // atomic per wave for exactly the number of waiting lanes (ballot), each
+        // lane's item = base + its prefix count (mbcnt).  Consecutive items are
+        // neighbouring pixels of an 8x8 tile, so refilled lanes stay coherent.
         // ------------------------------------------------------------------
         {
             bool need = (stage == ST_NEED_WORK);
             uint64_t mask = __ballot(need);
             while (mask != 0ull && !exhausted) {
-                if (cur >= end) {
-                    uint32_t base = 0u;
-                    if (__lane_id() == 0u) base = atomicAdd(a.queue, a.chunk);
-                    base = __builtin_amdgcn_readfirstlane(base);
-                    if (base >= a.n_items) { exhausted = true; break; }
-                    cur = base;
-                    end = min(base + a.chunk, a.n_items);
-                }
-                const uint32_t avail = end - cur;
                 const uint32_t cnt = (uint32_t)__popcll(mask);
+                uint32_t base = 0u;
+                if (__lane_id() == 0u) base = atomicAdd(a.queue, cnt);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base >= a.n_items) { exhausted = true; break; }
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                if (need && rank < avail) {
-                    const uint32_t item = cur + rank;
+                const uint32_t item = base + rank;
+                if (need && item < a.n_items) {
                     const uint32_t t = item >> 6, l = item & 63u;
                     const uint32_t tx = t % tiles_per_row, ty = t / tiles_per_row;
                     const uint32_t x = tx * 8u + (l & 7u);
@@ -386,7 +382,6 @@ k_render(const FrameArgs a)
                         gen_primary = true;
                     }
                 }
-                cur += min(cnt, avail);
                 need = (stage == ST_NEED_WORK);
                 mask = __ballot(need);
             }
