@@ -30,6 +30,8 @@ CONFIGS = {
                label="256^3 LSVO terrain, 1280x720, primary + 1 shadow ray"),
     "c3": dict(depth=9, width=1920, height=1080, spp=4, use_gi=1, aperture=0.0,
                label="512^3 LSVO terrain (FastNoise fixture), 1920x1080, 4 spp GI (1 indirect bounce), shadow_samples=1"),
+    "c3nogi": dict(depth=9, width=1920, height=1080, spp=4, use_gi=0, aperture=0.0,
+                   label="512^3 LSVO terrain, 1920x1080, 4 spp, primary + 1 shadow ray (no GI)"),
     "c4": dict(depth=9, width=1920, height=1080, spp=4, use_gi=1, aperture=0.5,
                label="512^3 LSVO terrain, 1920x1080, 4 spp GI + DOF (aperture 0.5)"),
     "c5": dict(depth=10, width=3840, height=2160, spp=16, use_gi=1, aperture=0.0,
@@ -79,7 +81,7 @@ def main():
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--pitch", type=float, default=-0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--tuning", default="", help="blocks_per_cu,refill_threshold")
+    ap.add_argument("--tuning", default="", help="blocks_per_cu,refill_threshold,chunk")
     args = ap.parse_args()
 
     import numpy as np

@@ -35,6 +35,7 @@ int fail(int code, const char* fmt, ...)
 struct Tuning {
     uint32_t blocks_per_cu = 4;
     uint32_t refill_threshold = 32;
+    uint32_t chunk = 64;
 } g_tuning;
 
 }  // namespace
@@ -91,11 +92,12 @@ static int require_device(int device, int* cu_count)
     return VRC_OK;
 }
 
-extern "C" int vrc_set_tuning(uint32_t blocks_per_cu, uint32_t refill_threshold)
+extern "C" int vrc_set_tuning(uint32_t blocks_per_cu, uint32_t refill_threshold, uint32_t chunk)
 {
     if (blocks_per_cu > 8 || refill_threshold > 64) return fail(VRC_ERR_INVALID, "tuning out of range");
     g_tuning.blocks_per_cu = blocks_per_cu ? blocks_per_cu : 4;
     g_tuning.refill_threshold = refill_threshold ? refill_threshold : 32;
+    g_tuning.chunk = chunk ? chunk : 64;
     return VRC_OK;
 }
 
@@ -347,6 +349,7 @@ extern "C" int vrc_render_frame(vrc_renderer* r, const vrc_camera* cam, const vr
     const uint64_t items = (uint64_t)tiles_per_row * ((rows + 7u) / 8u) * 64ull;
     if (items > 0xfffffff0ull) return fail(VRC_ERR_INVALID, "vrc_render_frame: frame too large");
     a.n_items = (uint32_t)items;
+    a.chunk = g_tuning.chunk;
     a.refill_threshold = g_tuning.refill_threshold;
     if (a.n_items == 0) return VRC_OK;
     HIP_TRY(hipMemsetAsync(a.queue, 0, 4, st));

@@ -15,6 +15,25 @@ namespace vrc {
 
 __device__ __forceinline__ float smax(float a, float b) { return (a < b) ? b : a; }  // std::max(a,b)
 __device__ __forceinline__ float smin(float a, float b) { return (b < a) ? b : a; }  // std::min(a,b)
+// Inside the walk every t value is finite-or-inf, never NaN (non-finite rays are
+// rejected in ray_setup; products px*t_coef are finite and differences of a
+// finite and an infinite value are infinite) and never -0 (a float difference is
+// -0 only for (-0) - (+0), and px*t_coef != 0).  On that domain std::min/max equal
+// IEEE minNum/maxNum, so the loop may use v_min_f32 / v_min3_f32 (1 instruction)
+// instead of v_cmp + v_cndmask (2): same bits.
+// (inline asm: via __builtin_fminf hipcc adds a canonicalising v_max x,x per operand.)
+__device__ __forceinline__ float tmin(float a, float b)
+{
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float tmin3(float a, float b, float c)
+{
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 __device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }       // utils.cpp:109-112
 __device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }       // utils.cpp:115-118
 // utils.cpp:60-64 std::modf fractional part: f - trunc(f) is exact; copysign keeps
@@ -126,12 +145,14 @@ __device__ __forceinline__ bool ray_setup(Ray& r, const uint2* __restrict__ node
 }
 
 // One iteration of the while loop at lsvo.hpp:72-146.  `stk` points at this
-// lane's column of the LDS stack, `stride` = lanes per row, so slot s lives at
+// lane's column of the LDS stack, STRIDE = lanes per row, so slot s lives at
 // stk[s*stride]; slots are (scale - DEPTH_OFFSET - 1) in [0, depth-2].
 // Returns the loop condition for the next iteration.
-__device__ __forceinline__ bool ray_step(Ray& r, const uint2* __restrict__ nodes, uint2* stk, int stride,
+template <int STRIDE>
+__device__ __forceinline__ bool ray_step(Ray& r, const uint2* __restrict__ nodes, uint2* stk,
                                          int depth, float coef, float bias)
 {
+    constexpr int stride = STRIDE;
     const int depth_off = SVO_MAX - depth;
     if (r.complexity >= MAX_ITERATIONS) return false;
     ++r.complexity;                                                     // :73
@@ -139,7 +160,7 @@ __device__ __forceinline__ bool ray_step(Ray& r, const uint2* __restrict__ nodes
     const float cx = r.px * r.tcx - r.tox;                              // :76
     const float cy = r.py * r.tcy - r.toy;
     const float cz = r.pz * r.tcz - r.toz;
-    const float tc_max = smin(cx, smin(cy, cz));                        // :77
+    const float tc_max = tmin3(cx, cy, cz);                             // :77
     const uint32_t child_shift = r.child_offset ^ r.mirror;            // :79
     const uint32_t masks = nd.x >> child_shift;                         // bit 8: child, bit 16: leaf
     if ((masks & 0x100u) && r.t_min <= r.t_max) {                       // :81
@@ -147,7 +168,7 @@ __device__ __forceinline__ bool ray_step(Ray& r, const uint2* __restrict__ nodes
             r.kind = 2u; r.shift = child_shift;
             return false;
         }
-        const float tv_max = smin(r.t_max, tc_max);                     // :86
+        const float tv_max = tmin(r.t_max, tc_max);                     // :86
         const float half = r.scale_f * 0.5f;                            // :87
         const float thx = half * r.tcx + cx;                            // :88
         const float thy = half * r.tcy + cy;

@@ -21,6 +21,7 @@ struct FrameArgs {
     uint32_t* queue;          // work-queue head
     uint32_t depth, width, height;
     uint32_t n_items;         // work items (8x8-tile order over this shard's rows)
+    uint32_t chunk;           // items a wave takes from the queue at once
     uint32_t refill_threshold;// leave the traversal loop once this many lanes wait
     vrc_camera cam;
     vrc_frame_params p;

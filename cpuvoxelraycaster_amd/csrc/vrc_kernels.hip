@@ -40,8 +40,7 @@ k_cast_rays(const uint2* __restrict__ nodes, int depth, uint64_t n,
     Ray r;
     bool active = ray_setup(r, nodes, ox, oy, oz, dx, dy, dz);
     uint2* stk = lds_stack + threadIdx.x;
-    const int stride = blockDim.x;
-    while (active) active = ray_step(r, nodes, stk, stride, depth, coef, bias);
+    while (active) active = ray_step<256>(r, nodes, stk, depth, coef, bias);
     Hit h;
     ray_finish(r, depth, ox, oy, oz, dx, dy, dz, h);
     // 48-byte record as three 16-byte stores
@@ -160,7 +159,6 @@ extern "C" __global__ void __launch_bounds__(VRC_RENDER_BLOCK)
 k_render(const FrameArgs a)
 {
     extern __shared__ uint2 lds_dyn[];                 // [depth-1][VRC_RENDER_BLOCK] stack, then 1536 B textures
-    const int stride = VRC_RENDER_BLOCK;
     uint2* stk = lds_dyn + threadIdx.x;
     uint8_t* tex = reinterpret_cast<uint8_t*>(lds_dyn + (a.depth - 1) * VRC_RENDER_BLOCK);
     for (uint32_t i = threadIdx.x; i < 1536u / 4u; i += VRC_RENDER_BLOCK)
@@ -178,7 +176,9 @@ k_render(const FrameArgs a)
     const uint32_t spp = a.p.spp ? a.p.spp : 1u;
     const uint32_t tiles_per_row = (W + 7u) / 8u;
 
-    bool exhausted = false;   // wave-uniform: the work queue has run dry
+    // wave-uniform work chunk [cur, end)
+    uint32_t cur = 0u, end = 0u;
+    bool exhausted = false;
 
     // per-lane pixel program state
     uint32_t stage = ST_NEED_WORK;
@@ -208,7 +208,7 @@ k_render(const FrameArgs a)
             if (act == 0ull) break;
             const uint64_t waiting = __ballot(!active && stage != ST_DONE);
             if ((uint32_t)__popcll(waiting) >= a.refill_threshold) break;
-            if (active) active = ray_step(r, nodes, stk, stride, depth, coef, 0.0f);
+            if (active) active = ray_step<VRC_RENDER_BLOCK>(r, nodes, stk, depth, coef, 0.0f);
         }
 
         // ------------------------------------------------------------------
@@ -352,23 +352,25 @@ k_render(const FrameArgs a)
         }
 
         // ------------------------------------------------------------------
-        // refill: the lanes without a pixel take consecutive work items -- one
-        // atomic per wave for exactly the number of waiting lanes (ballot), each
-        // lane's item = base + its prefix count (mbcnt).  Consecutive items are
-        // neighbouring pixels of an 8x8 tile, so refilled lanes stay coherent.
+        // refill: lanes without a pixel take consecutive work items
         // ------------------------------------------------------------------
         {
             bool need = (stage == ST_NEED_WORK);
             uint64_t mask = __ballot(need);
             while (mask != 0ull && !exhausted) {
+                if (cur >= end) {
+                    uint32_t base = 0u;
+                    if (__lane_id() == 0u) base = atomicAdd(a.queue, a.chunk);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (base >= a.n_items) { exhausted = true; break; }
+                    cur = base;
+                    end = min(base + a.chunk, a.n_items);
+                }
+                const uint32_t avail = end - cur;
                 const uint32_t cnt = (uint32_t)__popcll(mask);
-                uint32_t base = 0u;
-                if (__lane_id() == 0u) base = atomicAdd(a.queue, cnt);
-                base = __builtin_amdgcn_readfirstlane(base);
-                if (base >= a.n_items) { exhausted = true; break; }
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                const uint32_t item = base + rank;
-                if (need && item < a.n_items) {
+                if (need && rank < avail) {
+                    const uint32_t item = cur + rank;
                     const uint32_t t = item >> 6, l = item & 63u;
                     const uint32_t tx = t % tiles_per_row, ty = t / tiles_per_row;
                     const uint32_t x = tx * 8u + (l & 7u);
@@ -382,6 +384,7 @@ k_render(const FrameArgs a)
                         gen_primary = true;
                     }
                 }
+                cur += min(cnt, avail);
                 need = (stage == ST_NEED_WORK);
                 mask = __ballot(need);
             }

@@ -197,10 +197,12 @@ int vrc_unpack_shards(const void *gathered_dev, uint32_t width, uint32_t height,
 /* Host helper: generateRotationMatrix (utils.cpp:94-100) for Camera::setViewAngle. */
 void vrc_make_rotation(float angle_x, float angle_y, float rot[9]);
 
-/* Kernel tuning knobs of the persistent frame kernel; 0 = default.
+/* Tuning knobs of the persistent frame kernel; 0 = default.
  * blocks_per_cu: resident 256-thread workgroups per CU (default 4);
- * refill_threshold: waiting lanes per wave that trigger a refill (default 32). */
-int vrc_set_tuning(uint32_t blocks_per_cu, uint32_t refill_threshold);
+ * refill_threshold: waiting lanes per wave that trigger a refill (default 32);
+ * chunk: consecutive work items (pixels in 8x8-tile order) a wave reserves per
+ * queue atomic (default 64 = one tile: keeps a wave's lanes on one tile). */
+int vrc_set_tuning(uint32_t blocks_per_cu, uint32_t refill_threshold, uint32_t chunk);
 
 #ifdef __cplusplus
 }

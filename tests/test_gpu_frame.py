@@ -60,7 +60,7 @@ def run_pair(scene, textures, depth, W, H, pitch, spp=1, frames=1, use_gi=0, use
             fi += 1
     st = rc.stats()
     if tuning:
-        vrc.capi.check(vrc.capi.load().vrc_set_tuning(0, 0))
+        vrc.capi.check(vrc.capi.load().vrc_set_tuning(0, 0, 0))
     assert (st.rays, st.sum_complexity) == (rays, steps)
     if use_samples:
         assert np.array_equal(rc.readAccum(), oacc)
@@ -109,7 +109,7 @@ def test_odd_sizes(scene, textures):
     run_pair(scene, textures, 7, 7, 5, -0.8, spp=1, use_gi=0)
 
 
-@pytest.mark.parametrize("tuning", [(1, 1), (8, 64), (2, 17)])
+@pytest.mark.parametrize("tuning", [(1, 1, 64), (8, 64, 4096), (2, 32, 128)])
 def test_tuning_does_not_change_results(scene, textures, tuning):
     run_pair(scene, textures, 7, 160, 90, -0.5, spp=2, use_gi=1, tuning=tuning)
 

@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--frames", type=int, default=3)
     ap.add_argument("--bpc", default="4,8")
     ap.add_argument("--thr", default="1,8,16,32,48")
+    ap.add_argument("--chunk", default="64")
     ap.add_argument("--pitch", type=float, default=-0.5)
     args = ap.parse_args()
     import torch
@@ -31,7 +32,8 @@ def main():
     cam = vrc.reference_camera(depth, pitch=args.pitch, aperture=cfg["aperture"])
     stream = torch.cuda.current_stream().cuda_stream
     L = vrc.capi.load()
-    combos = list(itertools.product([int(v) for v in args.bpc.split(",")], [int(v) for v in args.thr.split(",")]))
+    combos = list(itertools.product([int(v) for v in args.bpc.split(",")], [int(v) for v in args.thr.split(",")],
+                                    [int(v) for v in args.chunk.split(",")]))
     times = {c: [] for c in combos}
     for r in range(args.rounds + 1):
         for c in combos:
@@ -48,10 +50,10 @@ def main():
                     times[c].append(e0.elapsed_time(e1))
     st = rc.stats(reset=True)
     print(f"config {args.config}: rays/frame ~ {st.rays // ((args.rounds + 1) * args.frames * len(combos))}")
-    print("bpc thr   median_ms  min_ms")
+    print("bpc thr chunk   median_ms  min_ms")
     for c in combos:
         t = sorted(times[c])
-        print(f"{c[0]:3d} {c[1]:3d}   {t[len(t) // 2]:8.3f} {t[0]:8.3f}")
+        print(f"{c[0]:3d} {c[1]:3d} {c[2]:5d}   {t[len(t) // 2]:8.3f} {t[0]:8.3f}")
 
 
 if __name__ == "__main__":
