@@ -144,74 +144,63 @@ __device__ __forceinline__ bool ray_setup(Ray& r, const uint2* __restrict__ node
     return finite3(ox, oy, oz) && finite3(dx, dy, dz);
 }
 
-// Iterations of the while loop at lsvo.hpp:72-146, grouped as the walk's own
-// grammar (DESCEND* ADVANCE): one call runs consecutive descend iterations
-// (:81-112) until a cell cannot be entered, then the one advance / pop iteration
-// that follows (:115-145).  Every lane executes exactly the reference's
-// sequence of iterations; grouping only decides where the lanes of a wave wait
-// for each other: lanes that drifted one iteration apart re-align at every
-// advance, so coherent rays (a pixel tile's primaries, their shadow rays) run
-// each phase together instead of serialising descend / advance / pop code in
-// every iteration.  The kernel is VALU-issue bound (rocprofv3: VALU pipe ~97 %
-// busy), so fewer issued wave-instructions is what counts.
-//
-// `stk` points at this lane's column of the LDS stack, STRIDE = lanes per row,
-// so slot s lives at stk[s*STRIDE]; slots are (scale - DEPTH_OFFSET - 1) in
-// [0, depth-2].  Returns the loop condition for the next iteration (false:
-// hit, miss, or iteration cap).
+// One iteration of the while loop at lsvo.hpp:72-146.  `stk` points at this
+// lane's column of the LDS stack, STRIDE = lanes per row, so slot s lives at
+// stk[s*stride]; slots are (scale - DEPTH_OFFSET - 1) in [0, depth-2].
+// Returns the loop condition for the next iteration.
 template <int STRIDE>
 __device__ __forceinline__ bool ray_step(Ray& r, const uint2* __restrict__ nodes, uint2* stk,
                                          int depth, float coef, float bias)
 {
+    constexpr int stride = STRIDE;
     const int depth_off = SVO_MAX - depth;
-    float cx, cy, cz, tc_max;
-    for (;;) {
-        if (r.complexity >= MAX_ITERATIONS) return false;
-        ++r.complexity;                                                     // :73
-        const uint2 nd = r.nd;                                              // :74
-        cx = r.px * r.tcx - r.tox;                                          // :76
-        cy = r.py * r.tcy - r.toy;
-        cz = r.pz * r.tcz - r.toz;
-        tc_max = tmin3(cx, cy, cz);                                         // :77
-        const uint32_t child_shift = r.child_offset ^ r.mirror;            // :79
-        const uint32_t masks = nd.x >> child_shift;                         // bit 8: child, bit 16: leaf
-        if (!((masks & 0x100u) && r.t_min <= r.t_max)) break;               // :81 -> advance
-        if (tc_max * coef + bias >= r.scale_f) {                            // :82-85
+    if (r.complexity >= MAX_ITERATIONS) return false;
+    ++r.complexity;                                                     // :73
+    const uint2 nd = r.nd;                                              // :74
+    const float cx = r.px * r.tcx - r.tox;                              // :76
+    const float cy = r.py * r.tcy - r.toy;
+    const float cz = r.pz * r.tcz - r.toz;
+    const float tc_max = tmin3(cx, cy, cz);                             // :77
+    const uint32_t child_shift = r.child_offset ^ r.mirror;            // :79
+    const uint32_t masks = nd.x >> child_shift;                         // bit 8: child, bit 16: leaf
+    if ((masks & 0x100u) && r.t_min <= r.t_max) {                       // :81
+        if (tc_max * coef + bias >= r.scale_f) {                        // :82-85
             r.kind = 2u; r.shift = child_shift;
             return false;
         }
-        const float tv_max = tmin(r.t_max, tc_max);                         // :86
-        if (!(r.t_min <= tv_max)) break;                                    // :89 -> advance
-        if (masks & 0x10000u) {                                             // :90-95
-            r.kind = 1u; r.shift = child_shift;
-            return false;
-        }
-        const float half = r.scale_f * 0.5f;                                // :87
-        const float thx = half * r.tcx + cx;                                // :88
+        const float tv_max = tmin(r.t_max, tc_max);                     // :86
+        const float half = r.scale_f * 0.5f;                            // :87
+        const float thx = half * r.tcx + cx;                            // :88
         const float thy = half * r.tcy + cy;
         const float thz = half * r.tcz + cz;
-        if (tc_max < r.h)                                                   // :97-100
-            stk[(r.scale - depth_off - 1) * STRIDE] = make_uint2(r.parent_id, f2u(r.t_max));
-        r.h = tc_max;                                                       // :101
-        r.parent_id += nd.y + child_shift;                                  // :103
-        r.nd = nodes[r.parent_id];
-        r.child_offset = 0u;
-        --r.scale;
-        r.scale_f = half;
-        if (thx > r.t_min) { r.child_offset ^= 1u; r.px += r.scale_f; }     // :107-109
-        if (thy > r.t_min) { r.child_offset ^= 2u; r.py += r.scale_f; }
-        if (thz > r.t_min) { r.child_offset ^= 4u; r.pz += r.scale_f; }
-        r.t_max = tv_max;                                                   // :110
-        if (!(r.scale > depth)) return false;                               // :72 (scale < 23 holds)
+        if (r.t_min <= tv_max) {                                        // :89
+            if (masks & 0x10000u) {                                     // :90-95
+                r.kind = 1u; r.shift = child_shift;
+                return false;
+            }
+            if (tc_max < r.h)                                           // :97-100
+                stk[(r.scale - depth_off - 1) * stride] = make_uint2(r.parent_id, f2u(r.t_max));
+            r.h = tc_max;                                               // :101
+            r.parent_id += nd.y + child_shift;                          // :103
+            r.nd = nodes[r.parent_id];
+            r.child_offset = 0u;
+            --r.scale;
+            r.scale_f = half;
+            if (thx > r.t_min) { r.child_offset ^= 1u; r.px += r.scale_f; }   // :107-109
+            if (thy > r.t_min) { r.child_offset ^= 2u; r.py += r.scale_f; }
+            if (thz > r.t_min) { r.child_offset ^= 4u; r.pz += r.scale_f; }
+            r.t_max = tv_max;                                           // :110
+            return r.scale > depth;                                     // :72 (scale < 23 holds)
+        }
     }
-    uint32_t step_mask = 0u;                                                // :115-118
+    uint32_t step_mask = 0u;                                            // :115-118
     if (cx <= tc_max) { step_mask ^= 1u; r.px -= r.scale_f; }
     if (cy <= tc_max) { step_mask ^= 2u; r.py -= r.scale_f; }
     if (cz <= tc_max) { step_mask ^= 4u; r.pz -= r.scale_f; }
-    r.t_min = tc_max;                                                       // :120
-    r.child_offset ^= step_mask;                                            // :121
-    r.normal = step_mask;                                                   // :122
-    if (r.child_offset & step_mask) {                                       // :124 pop
+    r.t_min = tc_max;                                                   // :120
+    r.child_offset ^= step_mask;                                        // :121
+    r.normal = step_mask;                                               // :122
+    if (r.child_offset & step_mask) {                                   // :124 pop
         uint32_t differing_bits = 0u;
         const uint32_t ipx = f2u(r.px), ipy = f2u(r.py), ipz = f2u(r.pz);
         if (step_mask & 1u) differing_bits |= ipx ^ f2u(r.px + r.scale_f);
@@ -227,15 +216,15 @@ __device__ __forceinline__ bool ray_step(Ray& r, const uint2* __restrict__ nodes
             // written stack[N] here and then leaves the loop (App. A.9).
             return false;
         }
-        r.scale_f = u2f((uint32_t)(r.scale - SVO_MAX + 127) << SVO_MAX);    // :133
-        const uint2 entry = stk[(r.scale - depth_off - 1) * STRIDE];        // :134-136
+        r.scale_f = u2f((uint32_t)(r.scale - SVO_MAX + 127) << SVO_MAX);  // :133
+        const uint2 entry = stk[(r.scale - depth_off - 1) * stride];     // :134-136
         r.parent_id = entry.x;
         r.nd = nodes[r.parent_id];
         r.t_max = u2f(entry.y);
         const uint32_t shx = ipx >> r.scale, shy = ipy >> r.scale, shz = ipz >> r.scale;  // :137-143
         r.px = u2f(shx << r.scale); r.py = u2f(shy << r.scale); r.pz = u2f(shz << r.scale);
         r.child_offset = (shx & 1u) | ((shy & 1u) << 1u) | ((shz & 1u) << 2u);
-        r.h = 0.0f;                                                         // :144
+        r.h = 0.0f;                                                      // :144
     }
     return true;
 }

@@ -155,10 +155,7 @@ __device__ __forceinline__ bool pixel_selected(const vrc_frame_params& p, uint32
 
 }  // namespace
 
-#ifndef VRC_RENDER_MIN_WAVES
-#define VRC_RENDER_MIN_WAVES 4   // waves per SIMD the register allocator must leave room for
-#endif
-extern "C" __global__ void __launch_bounds__(VRC_RENDER_BLOCK, VRC_RENDER_MIN_WAVES)
+extern "C" __global__ void __launch_bounds__(VRC_RENDER_BLOCK)
 k_render(const FrameArgs a)
 {
     extern __shared__ uint2 lds_dyn[];                 // [depth-1][VRC_RENDER_BLOCK] stack, then 1536 B textures
