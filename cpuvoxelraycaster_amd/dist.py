@@ -1,0 +1,73 @@
+"""Multi-GPU frame sharding: one process per GPU, the
+read-only LSVO replicated, the frame sharded by interleaved ROW_BLOCK-row
+blocks (block b belongs to rank b % world), RNG keyed by the global pixel index
+so the image does not depend on the GPU count.  The only exchange step is one
+all-gather of the resolved RGBA8 shards per frame (RCCL over xGMI on the GPU
+box; the same code runs over gloo on CPU tensors in the tests).
+
+Shard buffer layout (what vrc_pack_shard writes and vrc_unpack_shards reads):
+    gathered[rank][slot][row_in_block][x]  RGBA8, slot k <-> row block rank + k*world,
+    slots = ceil(ceil(H / ROW_BLOCK) / world), missing rows zero-padded.
+"""
+import numpy as np
+
+ROW_BLOCK = 8
+
+
+def shard_slots(height, row_block, world):
+    nblocks = (height + row_block - 1) // row_block
+    return (nblocks + world - 1) // world
+
+
+def shard_bytes(width, height, row_block, world):
+    return shard_slots(height, row_block, world) * row_block * width * 4
+
+
+def owned_rows(height, row_block, rank, world):
+    return [y for y in range(height) if (y // row_block) % world == rank]
+
+
+def pack_shard_np(image, row_block, rank, world):
+    """numpy restatement of k_pack_shard (CPU tests): image (H, W, 4) u8 -> flat shard."""
+    H, W, _ = image.shape
+    slots = shard_slots(H, row_block, world)
+    out = np.zeros((slots, row_block, W, 4), np.uint8)
+    for k in range(slots):
+        y0 = (k * world + rank) * row_block
+        if y0 < H:
+            n = min(row_block, H - y0)
+            out[k, :n] = image[y0:y0 + n]
+    return out.reshape(-1)
+
+
+def unpack_shards_np(gathered, width, height, row_block, world):
+    """numpy restatement of k_unpack_shards: flat [rank][slot][row][x] -> (H, W, 4)."""
+    slots = shard_slots(height, row_block, world)
+    g = np.asarray(gathered, np.uint8).reshape(world, slots, row_block, width, 4)
+    img = np.zeros((height, width, 4), np.uint8)
+    for y in range(height):
+        b = y // row_block
+        img[y] = g[b % world, b // world, y % row_block]
+    return img
+
+
+def all_gather_frame(mine, world):
+    """mine: this rank's packed shard (torch uint8 tensor, CPU or GPU).  Returns the
+    concatenation over ranks ([rank][slot]...) on every rank."""
+    import torch
+    import torch.distributed as dist
+    if world == 1:
+        return mine
+    gathered = torch.empty(world * mine.numel(), dtype=torch.uint8, device=mine.device)
+    dist.all_gather_into_tensor(gathered, mine)
+    return gathered
+
+
+def reduce_stats(values, device):
+    """Sum per-rank counters (rays, loop iterations, pixels) over ranks."""
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([int(v) for v in values], dtype=torch.int64, device=device)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [int(v) for v in t.tolist()]

@@ -1,0 +1,98 @@
+"""N > 1 path on CPU: two gloo processes each render their row-block shard of the
+frame (with the oracle standing in for the GPU renderer), pack it in the
+documented shard layout, all-gather, unpack -- the result must equal the
+unsharded frame, and summed counters must equal the unsharded counters."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, W, H, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle_lib as O
+    import cpuvoxelraycaster_amd.dist as vd
+    import cpuvoxelraycaster_amd.scenes as scenes
+    depth = 7
+    nodes = O.compile_terrain(depth, scenes.load_terrain_heights())
+    top, side = scenes.load_textures()
+    light = scenes.reference_light(depth)
+    cam = O.make_camera(scenes.reference_camera_position(depth), O.make_rotation(0.0, -0.5))
+    acc = None
+    rays = steps = 0
+    for s in range(2):
+        p = O.make_params(W, H, light, use_gi=1, use_samples=1, shadow_samples=1, frame_index=s,
+                          row_block=vd.ROW_BLOCK, shard_index=rank, shard_count=world)
+        _, acc, _, st = O.render_frame(nodes, depth, top, side, cam, p, accum=acc, threads=2)
+        rays += st.rays
+        steps += st.sum_complexity
+    img = O.samples_to_image(acc)
+    mine = torch.from_numpy(vd.pack_shard_np(img, vd.ROW_BLOCK, rank, world))
+    assert mine.numel() == vd.shard_bytes(W, H, vd.ROW_BLOCK, world)
+    gathered = vd.all_gather_frame(mine, world)
+    full = vd.unpack_shards_np(gathered.numpy(), W, H, vd.ROW_BLOCK, world)
+    tot = vd.reduce_stats([rays, steps], "cpu")
+    if rank == 0:
+        q.put((full, tot))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_frame_matches_unsharded(built, heights, textures):
+    import oracle_lib as O
+    import cpuvoxelraycaster_amd as vrc
+    W, H, world = 200, 100, 2   # 13 row blocks: uneven split, last block partial
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, W, H, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    full, tot = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    depth = 7
+    nodes = O.compile_terrain(depth, heights)
+    top, side = textures
+    cam = O.make_camera(vrc.reference_camera_position(depth), O.make_rotation(0.0, -0.5))
+    acc = None
+    rays = steps = 0
+    for s in range(2):
+        p = O.make_params(W, H, vrc.reference_light(depth), use_gi=1, use_samples=1, shadow_samples=1, frame_index=s)
+        _, acc, _, st = O.render_frame(nodes, depth, top, side, cam, p, accum=acc, threads=4)
+        rays += st.rays
+        steps += st.sum_complexity
+    assert np.array_equal(full, O.samples_to_image(acc))
+    assert tot == [rays, steps]
+
+
+def test_shard_layout_roundtrip():
+    import cpuvoxelraycaster_amd.dist as vd
+    rng = np.random.default_rng(0)
+    for (W, H, world) in [(17, 100, 3), (64, 64, 8), (5, 7, 2), (33, 1080, 8)]:
+        img = rng.integers(0, 256, (H, W, 4), dtype=np.uint8)
+        shards = [vd.pack_shard_np(img, vd.ROW_BLOCK, r, world) for r in range(world)]
+        assert all(s.size == vd.shard_bytes(W, H, vd.ROW_BLOCK, world) for s in shards)
+        back = vd.unpack_shards_np(np.concatenate(shards), W, H, vd.ROW_BLOCK, world)
+        assert np.array_equal(back, img)
+        rows = sorted(sum((vd.owned_rows(H, vd.ROW_BLOCK, r, world) for r in range(world)), []))
+        assert rows == list(range(H))
