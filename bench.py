@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--pitch", type=float, default=-0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tuning", default="", help="blocks_per_cu,refill_threshold,chunk")
+    ap.add_argument("--kernel", type=int, default=0, help="frame kernel: 0 tile-phased (default), 1 persistent mixed-stage")
     args = ap.parse_args()
 
     import numpy as np
@@ -106,6 +107,7 @@ def main():
         g.build()
     if args.tuning:
         vrc.capi.check(vrc.capi.load().vrc_set_tuning(*[int(v) for v in args.tuning.split(",")]))
+    vrc.capi.check(vrc.capi.load().vrc_set_kernel(args.kernel))
 
     cfg = CONFIGS[args.config]
     depth, W, H, spp = cfg["depth"], cfg["width"], cfg["height"], cfg["spp"]
@@ -213,7 +215,7 @@ def main():
                        + (", RCCL all-gather of RGBA8 shards" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
-                         "kernel": "k_render", "kernel_ms": round(kernel_ms, 4), "kernel_ms_max_rank": round(kernel_ms_max, 4),
+                         "kernel": "k_render_tile" if args.kernel == 0 else "k_render", "kernel_ms": round(kernel_ms, 4), "kernel_ms_max_rank": round(kernel_ms_max, 4),
                          "algorithmic_bytes_per_launch": int(alg_bytes)},
         }
         if world == 1 and not args.no_cpu_baseline:

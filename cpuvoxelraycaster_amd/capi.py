@@ -81,6 +81,7 @@ SYMBOLS = {
     "vrc_unpack_shards": (_int, [_vp, _u32, _u32, _u32, _u32, _vp, _vp]),
     "vrc_make_rotation": (None, [_f32, _f32, _vp]),
     "vrc_set_tuning": (_int, [_u32, _u32, _u32]),
+    "vrc_set_kernel": (_int, [_u32]),
 }
 
 _lib = None

@@ -36,6 +36,7 @@ struct Tuning {
     uint32_t blocks_per_cu = 4;
     uint32_t refill_threshold = 32;
     uint32_t chunk = 64;
+    uint32_t kernel = VRC_KERNEL_TILE;
 } g_tuning;
 
 }  // namespace
@@ -89,6 +90,13 @@ static int require_device(int device, int* cu_count)
         HIP_TRY(hipGetDeviceProperties(&prop, device));
         *cu_count = prop.multiProcessorCount;
     }
+    return VRC_OK;
+}
+
+extern "C" int vrc_set_kernel(uint32_t kernel)
+{
+    if (kernel > VRC_KERNEL_MIXED) return fail(VRC_ERR_INVALID, "unknown frame kernel %u", kernel);
+    g_tuning.kernel = kernel;
     return VRC_OK;
 }
 
@@ -354,9 +362,12 @@ extern "C" int vrc_render_frame(vrc_renderer* r, const vrc_camera* cam, const vr
     if (a.n_items == 0) return VRC_OK;
     HIP_TRY(hipMemsetAsync(a.queue, 0, 4, st));
     uint64_t want = (items + VRC_RENDER_BLOCK - 1) / VRC_RENDER_BLOCK;
-    const uint64_t cap = (uint64_t)s->cu_count * g_tuning.blocks_per_cu;
+    // k_render_tile needs ~43 KiB LDS per workgroup at depth 9: at most 3 fit a CU
+    const uint32_t bpc = g_tuning.kernel == VRC_KERNEL_TILE ? (g_tuning.blocks_per_cu < 3 ? g_tuning.blocks_per_cu : 3)
+                                                            : g_tuning.blocks_per_cu;
+    const uint64_t cap = (uint64_t)s->cu_count * bpc;
     const uint32_t grid = (uint32_t)(want < cap ? want : cap);
-    HIP_TRY(vrc::launch_render(a, grid, st));
+    HIP_TRY(vrc::launch_render(a, grid, (int)g_tuning.kernel, st));
     return VRC_OK;
 }
 

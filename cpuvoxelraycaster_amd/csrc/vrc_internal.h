@@ -7,6 +7,8 @@
 #include "../../include/vrc.h"
 
 #define VRC_RENDER_BLOCK 256
+#define VRC_KERNEL_TILE 0    // k_render_tile: tile-phased (default)
+#define VRC_KERNEL_MIXED 1   // k_render: persistent threads, mixed stages
 
 namespace vrc {
 
@@ -31,7 +33,7 @@ hipError_t launch_cast_rays(const void* nodes, int depth, uint64_t n, const floa
                             const float* coef, const float* bias, vrc_hit* out, hipStream_t st);
 hipError_t launch_grid_cast(const uint8_t* cells, int X, int Y, int Z, uint64_t n, const float* org, const float* dir,
                             vrc_hit* out, hipStream_t st);
-hipError_t launch_render(const FrameArgs& a, uint32_t grid_blocks, hipStream_t st);
+hipError_t launch_render(const FrameArgs& a, uint32_t grid_blocks, int kernel, hipStream_t st);
 hipError_t launch_resolve(const void* accum, void* image, uint32_t n, hipStream_t st);
 hipError_t launch_fill_u32(void* p, uint32_t value, uint64_t n, hipStream_t st);
 hipError_t launch_pack_shard(const void* image, uint32_t W, uint32_t H, uint32_t row_block, uint32_t shard,

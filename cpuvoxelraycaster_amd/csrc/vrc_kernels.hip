@@ -445,6 +445,332 @@ k_render(const FrameArgs a)
 }
 
 // ---------------------------------------------------------------------------
+// R0 + S1..S4, tile-phased: coherent rays in lockstep, GI rays from an LDS pool
+// ---------------------------------------------------------------------------
+//
+// One wave owns one 8x8 pixel tile at a time (tile index from a global queue)
+// and runs it in two phases per pass of up to TILE_SPP samples:
+//
+//   phase A  every lane: camera ray -> walk -> shade -> shadow ray(s) -> walk.
+//            The 64 primaries of a tile (and their shadow rays) visit nearly the
+//            same nodes, so the wave stays in lockstep and executes one of the
+//            descend / advance / pop paths per iteration instead of all three
+//            (rocprofv3: 72 % lane utilisation vs 34 % with mixed stages).
+//            Pixel-samples that need GI are compacted into a per-wave job pool
+//            in LDS with ballot + prefix sum (mbcnt) -- "ray compaction between
+//            bounces" without a trip through HBM.
+//   phase B  lanes pull GI jobs from the pool (wave-uniform cursor, ballot +
+//            prefix sum again), each job = GI ray + its shadow ray (+ the
+//            second bounce of the extension); these rays are incoherent and
+//            short, so lanes are refilled as soon as `refill_threshold` of them
+//            wait.  Only GI stages exist here, which keeps the transition code
+//            (executed at partial utilisation) short.
+//
+// Per-lane float arithmetic and its order are exactly those of k_render and of
+// the oracle; only the schedule differs.
+
+namespace {
+constexpr uint32_t TILE_SPP = 4u;                    // samples per pass (pool = 64 * TILE_SPP jobs)
+constexpr uint32_t TILE_POOL = 64u * TILE_SPP;
+constexpr uint32_t TILE_WAVE_LDS = TILE_POOL * 4u * 6u + TILE_POOL;   // px,py,pz,an,li,colors (u32) + meta (u8)
+}  // namespace
+
+extern "C" __global__ void __launch_bounds__(VRC_RENDER_BLOCK)
+k_render_tile(const FrameArgs a)
+{
+    extern __shared__ uint2 lds_dyn[];   // [depth-1][256] stack | 4 x per-wave pool | 1536 B textures
+    uint2* stk = lds_dyn + threadIdx.x;
+    uint8_t* lds_tail = reinterpret_cast<uint8_t*>(lds_dyn + (a.depth - 1) * VRC_RENDER_BLOCK);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    float* pool_px = reinterpret_cast<float*>(lds_tail + wave * TILE_WAVE_LDS);
+    float* pool_py = pool_px + TILE_POOL;
+    float* pool_pz = pool_py + TILE_POOL;
+    uint32_t* pool_an = reinterpret_cast<uint32_t*>(pool_pz + TILE_POOL);   // albedo | normal mask<<24 | normal signs<<27
+    float* pool_li = reinterpret_cast<float*>(pool_an + TILE_POOL);
+    uint32_t* colors = reinterpret_cast<uint32_t*>(pool_li + TILE_POOL);    // final colour of sample si, lane l at [si*64+l]
+    uint8_t* pool_meta = reinterpret_cast<uint8_t*>(colors + TILE_POOL);    // lane | si<<6
+    uint8_t* tex = lds_tail + 4u * TILE_WAVE_LDS;
+    for (uint32_t i = threadIdx.x; i < 1536u / 4u; i += VRC_RENDER_BLOCK)
+        reinterpret_cast<uint32_t*>(tex)[i] = reinterpret_cast<const uint32_t*>(a.tex)[i];
+    __syncthreads();
+
+    const uint2* __restrict__ nodes = a.nodes;
+    const int depth = (int)a.depth;
+    const uint32_t W = a.width, H = a.height;
+    const float inv_size = 1.0f / (float)(1u << a.depth);                 // main.cpp:82
+    const float n_normalizer = inv_size * 0.0078125f * 2.0f;              // raycaster.hpp:171-172
+    const float lx = a.p.light_position[0], ly = a.p.light_position[1], lz = a.p.light_position[2];
+    const uint32_t shadow_samples = a.p.shadow_samples ? a.p.shadow_samples : (a.p.use_samples ? 4u : 1u);
+    const uint32_t gi_bounces = a.p.gi_bounces ? a.p.gi_bounces : 1u;
+    const uint32_t spp = a.p.spp ? a.p.spp : 1u;
+    const uint32_t tiles_per_row = (W + 7u) / 8u;
+    const uint32_t n_tiles = a.n_items >> 6;
+    const bool sharded = a.p.row_block && a.p.shard_count > 1u;
+
+    uint32_t n_rays = 0u, n_steps = 0u, n_hits = 0u, n_pix = 0u;
+
+    for (;;) {
+        uint32_t tile = 0u;
+        if (lane == 0u) tile = atomicAdd(a.queue, 1u);
+        tile = __builtin_amdgcn_readfirstlane(tile);
+        if (tile >= n_tiles) break;
+        const uint32_t tx = tile % tiles_per_row, ty = tile / tiles_per_row;
+        const uint32_t px_x = tx * 8u + (lane & 7u);
+        uint32_t px_y = ty * 8u + (lane >> 3);
+        if (sharded) px_y = ((px_y / a.p.row_block) * a.p.shard_count + a.p.shard_index) * a.p.row_block + (px_y % a.p.row_block);
+        const bool valid = px_x < W && px_y < H && pixel_selected(a.p, W, H, px_x, px_y);
+        const uint32_t pix = px_y * W + px_x;
+        uint32_t acc_r = 0u, acc_g = 0u, acc_b = 0u;
+
+        for (uint32_t s0 = 0u; s0 < spp; s0 += TILE_SPP) {
+            const uint32_t ns = min(TILE_SPP, spp - s0);
+            uint32_t njobs = 0u;   // wave-uniform
+
+            // ---------------- phase A: primary + shadow, lockstep ----------------
+            for (uint32_t si = 0u; si < ns; ++si) {
+                const uint32_t sample = s0 + si;
+                const uint32_t fr = a.p.frame_index + sample;
+                bool hit = false;
+                uint32_t albedo = 0u;
+                float light_intensity = 0.0f;
+                Hit h;
+                h.hit = 0u; h.px = h.py = h.pz = 0.0f; h.nx = h.ny = h.nz = 0.0f;
+                if (valid) {
+                    // R0: main.cpp:133,145-149; camera_controller.hpp:34-54
+                    const float aspect_ratio = (float)W / (float)H;
+                    const float lens_x = (float)px_x / (float)H - aspect_ratio * 0.5f;
+                    const float lens_y = (float)px_y / (float)H - 0.5f;
+                    float sx = lens_x, sy = lens_y, sz = a.cam.fov;
+                    normalize3(sx, sy, sz);
+                    const float fx = sx * a.cam.focal_length, fy = sy * a.cam.focal_length, fz = sz * a.cam.focal_length;
+                    const float r0 = get_rand(counter_rand(a.p.seed, fr, pix, 0u), -0.5f, 0.5f);
+                    const float r1 = get_rand(counter_rand(a.p.seed, fr, pix, 1u), -0.5f, 0.5f);
+                    const float rvx = a.cam.aperture * r0, rvy = a.cam.aperture * r1, rvz = a.cam.aperture * 0.0f;
+                    float vx = fx - rvx, vy = fy - rvy, vz = fz - rvz;
+                    normalize3(vx, vy, vz);
+                    const float* m = a.cam.rot;
+                    float dx = (m[0] * vx + m[1] * vy) + m[2] * vz;
+                    float dy = (m[3] * vx + m[4] * vy) + m[5] * vz;
+                    float dz = (m[6] * vx + m[7] * vy) + m[8] * vz;
+                    const float wx = (m[0] * rvx + m[1] * rvy) + m[2] * rvz;
+                    const float wy = (m[3] * rvx + m[4] * rvy) + m[5] * rvz;
+                    const float wz = (m[6] * rvx + m[7] * rvy) + m[8] * rvz;
+                    float ox = (a.cam.position[0] + wx) * inv_size + 1.0f;
+                    float oy = (a.cam.position[1] + wy) * inv_size + 1.0f;
+                    float oz = (a.cam.position[2] + wz) * inv_size + 1.0f;
+                    Ray r;
+                    bool active = ray_setup(r, nodes, ox, oy, oz, dx, dy, dz);
+                    while (active) active = ray_step<VRC_RENDER_BLOCK>(r, nodes, stk, depth, 0.0f, 0.0f);
+                    n_rays += 1u; n_steps += r.complexity;
+                    ray_finish(r, depth, ox, oy, oz, dx, dy, dz, h);               // raycaster.hpp:131
+                    if (a.prim && sample == 0u) {
+                        uint4* o = reinterpret_cast<uint4*>(a.prim + pix);
+                        o[0] = make_uint4(f2u(h.px), f2u(h.py), f2u(h.pz), f2u(h.nx));
+                        o[1] = make_uint4(f2u(h.ny), f2u(h.nz), f2u(h.u), f2u(h.v));
+                        o[2] = make_uint4(h.hit, h.node, f2u(h.distance), h.complexity);
+                    }
+                    if (h.hit) {
+                        hit = true;
+                        n_hits += 1u;
+                        // raycaster.hpp:209-240 albedo
+                        const uint8_t* img = (h.ny != 0.0f) ? tex : tex + 768;
+                        const float tu = clampf_(h.u, 0.0f, 1.0f), tv = clampf_(h.v, 0.0f, 1.0f);
+                        uint32_t idx = (uint32_t)(16.0f * tu) + (uint32_t)(16.0f * tv) * 16u;
+                        idx = min(idx, 255u);
+                        albedo = (uint32_t)img[idx * 3] | ((uint32_t)img[idx * 3 + 1] << 8) | ((uint32_t)img[idx * 3 + 2] << 16);
+                        // raycaster.hpp:139,150-158 shadow ray(s): the reference re-casts the identical ray
+                        ox = h.px + h.nx * inv_size * 0.001f;
+                        oy = h.py + h.ny * inv_size * 0.001f;
+                        oz = h.pz + h.nz * inv_size * 0.001f;
+                        for (uint32_t i = shadow_samples; i--;) {
+                            dx = lx - ox; dy = ly - oy; dz = lz - oz;
+                            normalize3(dx, dy, dz);
+                            const float lit = smax(0.0f, dot3(dx, dy, dz, h.nx, h.ny, h.nz));   // :156
+                            active = ray_setup(r, nodes, ox, oy, oz, dx, dy, dz);
+                            while (active) active = ray_step<VRC_RENDER_BLOCK>(r, nodes, stk, depth, 0.0f, 0.0f);
+                            n_rays += 1u; n_steps += r.complexity;
+                            if (!r.kind) light_intensity = lit;                              // :155-157
+                        }
+                    }
+                }
+                if (a.p.use_gi) {
+                    // compact the pixel-samples that continue with GI into the wave's job pool
+                    const bool job = valid && hit;
+                    const uint64_t mask = __ballot(job);
+                    const uint32_t slot = njobs + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                    if (job) {
+                        pool_px[slot] = h.px; pool_py[slot] = h.py; pool_pz[slot] = h.pz;
+                        // normal components are +-(0,1,2,4): 3 mask bits + 3 sign bits restore them exactly
+                        const uint32_t nm = (h.nx != 0.0f ? 1u : 0u) | (h.ny != 0.0f ? 2u : 0u) | (h.nz != 0.0f ? 4u : 0u);
+                        const uint32_t sg = (f2u(h.nx) >> 31) | ((f2u(h.ny) >> 31) << 1) | ((f2u(h.nz) >> 31) << 2);
+                        pool_an[slot] = albedo | (nm << 24) | (sg << 27);
+                        pool_li[slot] = light_intensity;
+                        pool_meta[slot] = (uint8_t)(lane | (si << 6));
+                    } else {
+                        colors[si * 64u + lane] = 0u;                                // miss -> sf::Color::Black
+                    }
+                    njobs += (uint32_t)__popcll(mask);
+                } else {
+                    colors[si * 64u + lane] = hit ? color_mult(albedo, smin(1.0f, smax(0.0f, light_intensity + 0.0f))) : 0u;  // :161-163
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+
+            // ---------------- phase B: GI jobs from the pool ----------------
+            if (a.p.use_gi && njobs != 0u) {
+                uint32_t next = 0u;            // wave-uniform pool cursor
+                uint32_t stage = ST_NEED_WORK; // ST_GI / ST_GI_SHADOW / ST_NEED_WORK / ST_DONE
+                uint32_t jmeta = 0u, jpix = 0u, jan = 0u, draw = 0u, gi_level = 0u;
+                float jlight = 0.0f;
+                float base_px = 0, base_py = 0, base_pz = 0, base_nx = 0, base_ny = 0, base_nz = 0;
+                float pending = 0.0f, dot_gi = 0.0f, dot_gi0 = 0.0f, acc0 = 0.0f, acc1 = 0.0f;
+                float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0;
+                Ray r;
+                bool active = false;
+                for (;;) {
+                    for (;;) {
+                        const uint64_t act = __ballot(active);
+                        if (act == 0ull) break;
+                        const uint64_t waiting = __ballot(!active && stage != ST_DONE);
+                        if ((uint32_t)__popcll(waiting) >= a.refill_threshold) break;
+                        if (active) active = ray_step<VRC_RENDER_BLOCK>(r, nodes, stk, depth, 0.5f, 0.0f);
+                    }
+                    bool launch = false, gen_gi = false, job_done = false;
+                    if (!active && (stage == ST_GI || stage == ST_GI_SHADOW)) {
+                        n_rays += 1u; n_steps += r.complexity;
+                        if (stage == ST_GI) {
+                            Hit g;
+                            ray_finish(r, depth, ox, oy, oz, dx, dy, dz, g);
+                            if (g.hit) {                                             // raycaster.hpp:195-198
+                                base_px = g.px; base_py = g.py; base_pz = g.pz;
+                                base_nx = g.nx; base_ny = g.ny; base_nz = g.nz;
+                                ox = g.px + g.nx * n_normalizer;
+                                oy = g.py + g.ny * n_normalizer;
+                                oz = g.pz + g.nz * n_normalizer;
+                                dx = lx - ox; dy = ly - oy; dz = lz - oz;
+                                normalize3(dx, dy, dz);
+                                const float dotl = dot3(g.nx, g.ny, g.nz, dx, dy, dz);                 // :200
+                                pending = 1000000.0f * smin(0.5f, smax(0.0f, dotl) * dot_gi);          // :201
+                                stage = ST_GI_SHADOW;
+                                launch = true;
+                            } else {
+                                job_done = true;
+                            }
+                        } else {
+                            if (gi_level == 0u) { if (!r.kind) acc0 += pending; }
+                            else                { if (!r.kind) acc1 += pending; }
+                            if (gi_level + 1u < gi_bounces) { dot_gi0 = dot_gi; gi_level += 1u; gen_gi = true; }
+                            else job_done = true;
+                        }
+                        if (job_done) {
+                            // raycaster.hpp:206 + nested extension, then :163
+                            float gi;
+                            if (gi_level == 0u) gi = smax(0.0f, acc0 / 1.0f);
+                            else { acc0 += dot_gi0 * smax(0.0f, acc1 / 1.0f); gi = smax(0.0f, acc0 / 1.0f); }
+                            colors[(jmeta >> 6) * 64u + (jmeta & 63u)] =
+                                color_mult(jan & 0xffffffu, smin(1.0f, smax(0.0f, jlight + gi)));
+                            stage = ST_NEED_WORK;
+                        }
+                    }
+                    // refill from the pool: waiting lanes take consecutive jobs
+                    {
+                        const bool need = (stage == ST_NEED_WORK);
+                        const uint64_t mask = __ballot(need);
+                        if (mask != 0ull) {
+                            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                            const uint32_t j = next + rank;
+                            if (need) {
+                                if (j < njobs) {
+                                    jmeta = pool_meta[j];
+                                    jan = pool_an[j];
+                                    jlight = pool_li[j];
+                                    base_px = pool_px[j]; base_py = pool_py[j]; base_pz = pool_pz[j];
+                                    const uint32_t nm = (jan >> 24) & 7u, sg = (jan >> 27) & 7u;
+                                    base_nx = u2f(((sg & 1u) << 31) | ((nm & 1u) ? 0x3f800000u : 0u));
+                                    base_ny = u2f((((sg >> 1) & 1u) << 31) | ((nm & 2u) ? 0x40000000u : 0u));
+                                    base_nz = u2f((((sg >> 2) & 1u) << 31) | ((nm & 4u) ? 0x40800000u : 0u));
+                                    const uint32_t jl = jmeta & 63u;
+                                    const uint32_t jx = tx * 8u + (jl & 7u);
+                                    uint32_t jy = ty * 8u + (jl >> 3);
+                                    if (sharded) jy = ((jy / a.p.row_block) * a.p.shard_count + a.p.shard_index) * a.p.row_block + (jy % a.p.row_block);
+                                    jpix = jy * W + jx;
+                                    draw = 2u; gi_level = 0u; acc0 = 0.0f; acc1 = 0.0f;
+                                    gen_gi = true;
+                                } else {
+                                    stage = ST_DONE;
+                                }
+                            }
+                            next = min(njobs, next + (uint32_t)__popcll(mask));
+                        }
+                    }
+                    if (gen_gi) {
+                        // raycaster.hpp:174-194: GI ray from (base_p, base_n)
+                        const uint32_t fr = a.p.frame_index + s0 + (jmeta >> 6);
+                        ox = base_px + base_nx * n_normalizer;
+                        oy = base_py + base_ny * n_normalizer;
+                        oz = base_pz + base_nz * n_normalizer;
+                        const float c1 = get_rand(counter_rand(a.p.seed, fr, jpix, draw), -1000.0f, 1000.0f);
+                        const float c2 = get_rand(counter_rand(a.p.seed, fr, jpix, draw + 1u), -1000.0f, 1000.0f);
+                        draw += 2u;
+                        float qx = 0.0f, qy = 0.0f, qz = 0.0f;
+                        if (base_nx != 0.0f)      { qy = c1; qz = c2; }
+                        else if (base_ny != 0.0f) { qx = c1; qz = c2; }
+                        else if (base_nz != 0.0f) { qx = c1; qy = c2; }
+                        dx = (base_nx + qx) * n_normalizer;
+                        dy = (base_ny + qy) * n_normalizer;
+                        dz = (base_nz + qz) * n_normalizer;
+                        normalize3(dx, dy, dz);
+                        dot_gi = dot3(dx, dy, dz, base_nx, base_ny, base_nz);        // :193
+                        stage = ST_GI;
+                        launch = true;
+                    }
+                    if (launch) active = ray_setup(r, nodes, ox, oy, oz, dx, dy, dz);
+                    if (__ballot(stage != ST_DONE) == 0ull) break;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+
+            // ---------------- sink: raycaster.hpp:77-91, samples in order ----------------
+            if (valid) {
+                n_pix += ns;
+                for (uint32_t si = 0u; si < ns; ++si) {
+                    const uint32_t c = colors[si * 64u + lane];
+                    if (a.p.use_samples) { acc_r += c & 0xffu; acc_g += (c >> 8) & 0xffu; acc_b += (c >> 16) & 0xffu; }
+                    else {
+                        uint32_t old = reinterpret_cast<uint32_t*>(a.image)[pix];
+                        const uint32_t alpha = old & 0xff000000u;
+                        old = color_mult(old & 0xffffffu, 0.4f);
+                        const uint32_t nw = color_mult(c, 1.0f - 0.4f);
+                        reinterpret_cast<uint32_t*>(a.image)[pix] = color_add_sat(old, nw) | alpha;
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        }
+        if (valid && a.p.use_samples) {
+            uint4* ap = reinterpret_cast<uint4*>(a.accum) + pix;                     // raycaster.hpp:87-90
+            uint4 v = *ap;
+            v.x += acc_r; v.y += acc_g; v.z += acc_b; v.w += spp;
+            *ap = v;
+        }
+    }
+
+    uint64_t s_rays = n_rays, s_steps = n_steps, s_hits = n_hits, s_pix = n_pix;
+    for (int off = 32; off > 0; off >>= 1) {
+        s_rays += __shfl_down(s_rays, off);
+        s_steps += __shfl_down(s_steps, off);
+        s_hits += __shfl_down(s_hits, off);
+        s_pix += __shfl_down(s_pix, off);
+    }
+    if (lane == 0u) {
+        atomicAdd(reinterpret_cast<unsigned long long*>(a.stats + 0), (unsigned long long)s_rays);
+        atomicAdd(reinterpret_cast<unsigned long long*>(a.stats + 1), (unsigned long long)s_steps);
+        atomicAdd(reinterpret_cast<unsigned long long*>(a.stats + 2), (unsigned long long)s_hits);
+        atomicAdd(reinterpret_cast<unsigned long long*>(a.stats + 3), (unsigned long long)s_pix);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // S4 sink + plumbing
 // ---------------------------------------------------------------------------
 
@@ -519,10 +845,15 @@ hipError_t launch_grid_cast(const uint8_t* cells, int X, int Y, int Z, uint64_t 
     return hipGetLastError();
 }
 
-hipError_t launch_render(const FrameArgs& a, uint32_t grid_blocks, hipStream_t st)
+hipError_t launch_render(const FrameArgs& a, uint32_t grid_blocks, int kernel, hipStream_t st)
 {
-    const size_t lds = (size_t)(a.depth - 1) * VRC_RENDER_BLOCK * sizeof(uint2) + 1536;
-    hipLaunchKernelGGL(k_render, dim3(grid_blocks), dim3(VRC_RENDER_BLOCK), lds, st, a);
+    if (kernel == VRC_KERNEL_MIXED) {
+        const size_t lds = (size_t)(a.depth - 1) * VRC_RENDER_BLOCK * sizeof(uint2) + 1536;
+        hipLaunchKernelGGL(k_render, dim3(grid_blocks), dim3(VRC_RENDER_BLOCK), lds, st, a);
+    } else {
+        const size_t lds = (size_t)(a.depth - 1) * VRC_RENDER_BLOCK * sizeof(uint2) + 4 * TILE_WAVE_LDS + 1536;
+        hipLaunchKernelGGL(k_render_tile, dim3(grid_blocks), dim3(VRC_RENDER_BLOCK), lds, st, a);
+    }
     return hipGetLastError();
 }
 

@@ -10,6 +10,16 @@ import oracle_lib as O
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=[0, 1], ids=["tile", "mixed"])
+def frame_kernel(request, built):
+    """Every frame test runs on both frame kernels (vrc_set_kernel): 0 = tile-phased
+    (default), 1 = persistent threads with mixed stages."""
+    import cpuvoxelraycaster_amd as vrc
+    vrc.capi.check(vrc.capi.load().vrc_set_kernel(request.param))
+    yield request.param
+    vrc.capi.check(vrc.capi.load().vrc_set_kernel(0))
+
+
 @pytest.fixture(scope="module")
 def scene(built, heights, textures):
     import cpuvoxelraycaster_amd as vrc

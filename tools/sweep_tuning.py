@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--thr", default="1,8,16,32,48")
     ap.add_argument("--chunk", default="64")
     ap.add_argument("--pitch", type=float, default=-0.5)
+    ap.add_argument("--kernel", default="0", help="frame kernels to sweep: 0 tile-phased, 1 mixed")
     args = ap.parse_args()
     import torch
     import bench
@@ -32,12 +33,13 @@ def main():
     cam = vrc.reference_camera(depth, pitch=args.pitch, aperture=cfg["aperture"])
     stream = torch.cuda.current_stream().cuda_stream
     L = vrc.capi.load()
-    combos = list(itertools.product([int(v) for v in args.bpc.split(",")], [int(v) for v in args.thr.split(",")],
-                                    [int(v) for v in args.chunk.split(",")]))
+    combos = list(itertools.product([int(v) for v in args.kernel.split(",")], [int(v) for v in args.bpc.split(",")],
+                                    [int(v) for v in args.thr.split(",")], [int(v) for v in args.chunk.split(",")]))
     times = {c: [] for c in combos}
     for r in range(args.rounds + 1):
         for c in combos:
-            vrc.capi.check(L.vrc_set_tuning(*c))
+            vrc.capi.check(L.vrc_set_kernel(c[0]))
+            vrc.capi.check(L.vrc_set_tuning(*c[1:]))
             for f in range(args.frames):
                 rc.resetSamples(stream)
                 rc.frame_index = 0
@@ -50,10 +52,10 @@ def main():
                     times[c].append(e0.elapsed_time(e1))
     st = rc.stats(reset=True)
     print(f"config {args.config}: rays/frame ~ {st.rays // ((args.rounds + 1) * args.frames * len(combos))}")
-    print("bpc thr chunk   median_ms  min_ms")
+    print("krn bpc thr chunk   median_ms  min_ms")
     for c in combos:
         t = sorted(times[c])
-        print(f"{c[0]:3d} {c[1]:3d} {c[2]:5d}   {t[len(t) // 2]:8.3f} {t[0]:8.3f}")
+        print(f"{c[0]:3d} {c[1]:3d} {c[2]:3d} {c[3]:5d}   {t[len(t) // 2]:8.3f} {t[0]:8.3f}")
 
 
 if __name__ == "__main__":
