@@ -193,6 +193,7 @@ __device__ __forceinline__ bool ray_step(Ray& r, const uint2* __restrict__ nodes
             return r.scale > depth;                                     // :72 (scale < 23 holds)
         }
     }
+    const uint32_t opx = f2u(r.px), opy = f2u(r.py), opz = f2u(r.pz);   // pos before the step
     uint32_t step_mask = 0u;                                            // :115-118
     if (cx <= tc_max) { step_mask ^= 1u; r.px -= r.scale_f; }
     if (cy <= tc_max) { step_mask ^= 2u; r.py -= r.scale_f; }
@@ -201,11 +202,12 @@ __device__ __forceinline__ bool ray_step(Ray& r, const uint2* __restrict__ nodes
     r.child_offset ^= step_mask;                                        // :121
     r.normal = step_mask;                                               // :122
     if (r.child_offset & step_mask) {                                   // :124 pop
-        uint32_t differing_bits = 0u;
+        // :125-131 differing_bits = OR over the stepped axes of bits(pos) ^ bits(pos + scale_f).
+        // pos and scale_f are exact multiples of 2^-23 in [0.5, 2), so pos - scale_f + scale_f
+        // is bit-identical to the pre-step pos: the XOR against the saved bits is the same
+        // value, and it is 0 on the axes that did not step -- no per-axis select needed.
         const uint32_t ipx = f2u(r.px), ipy = f2u(r.py), ipz = f2u(r.pz);
-        if (step_mask & 1u) differing_bits |= ipx ^ f2u(r.px + r.scale_f);
-        if (step_mask & 2u) differing_bits |= ipy ^ f2u(r.py + r.scale_f);
-        if (step_mask & 4u) differing_bits |= ipz ^ f2u(r.pz + r.scale_f);
+        const uint32_t differing_bits = (ipx ^ opx) | (ipy ^ opy) | (ipz ^ opz);
         // :132 -- exponent of (float)differing_bits.  pos stays in [0.5, 2) so
         // differing_bits < 2^24 converts exactly and the exponent is the index
         // of the highest set bit.  differing_bits == 0 (unreachable, UB in the
@@ -217,13 +219,14 @@ __device__ __forceinline__ bool ray_step(Ray& r, const uint2* __restrict__ nodes
             return false;
         }
         r.scale_f = u2f((uint32_t)(r.scale - SVO_MAX + 127) << SVO_MAX);  // :133
-        const uint2 entry = stk[(r.scale - depth_off - 1) * stride];     // :134-136
+        const uint2 entry = stk[(r.scale - depth_off - 1) * STRIDE];     // :134-136
         r.parent_id = entry.x;
         r.nd = nodes[r.parent_id];
         r.t_max = u2f(entry.y);
-        const uint32_t shx = ipx >> r.scale, shy = ipy >> r.scale, shz = ipz >> r.scale;  // :137-143
-        r.px = u2f(shx << r.scale); r.py = u2f(shy << r.scale); r.pz = u2f(shz << r.scale);
-        r.child_offset = (shx & 1u) | ((shy & 1u) << 1u) | ((shz & 1u) << 2u);
+        // :137-143  (i >> scale) << scale == i & (~0 << scale); child bit = bit `scale` of i
+        const uint32_t keep = 0xffffffffu << r.scale;
+        r.px = u2f(ipx & keep); r.py = u2f(ipy & keep); r.pz = u2f(ipz & keep);
+        r.child_offset = ((ipx >> r.scale) & 1u) | (((ipy >> r.scale) & 1u) << 1u) | (((ipz >> r.scale) & 1u) << 2u);
         r.h = 0.0f;                                                      // :144
     }
     return true;
