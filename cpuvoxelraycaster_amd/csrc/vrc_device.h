@@ -152,7 +152,6 @@ template <int STRIDE>
 __device__ __forceinline__ bool ray_step(Ray& r, const uint2* __restrict__ nodes, uint2* stk,
                                          int depth, float coef, float bias)
 {
-    constexpr int stride = STRIDE;
     const int depth_off = SVO_MAX - depth;
     if (r.complexity >= MAX_ITERATIONS) return false;
     ++r.complexity;                                                     // :73
@@ -163,35 +162,35 @@ __device__ __forceinline__ bool ray_step(Ray& r, const uint2* __restrict__ nodes
     const float tc_max = tmin3(cx, cy, cz);                             // :77
     const uint32_t child_shift = r.child_offset ^ r.mirror;            // :79
     const uint32_t masks = nd.x >> child_shift;                         // bit 8: child, bit 16: leaf
-    if ((masks & 0x100u) && r.t_min <= r.t_max) {                       // :81
-        if (tc_max * coef + bias >= r.scale_f) {                        // :82-85
-            r.kind = 2u; r.shift = child_shift;
-            return false;
-        }
-        const float tv_max = tmin(r.t_max, tc_max);                     // :86
+    // The nested tests of :81-95 as flat predicates (same comparisons, same order of
+    // evaluation where it matters: every operand is a plain value, no side effects).
+    const bool exists = (masks & 0x100u) && r.t_min <= r.t_max;        // :81
+    const bool lod = exists && (tc_max * coef + bias >= r.scale_f);     // :82
+    const float tv_max = tmin(r.t_max, tc_max);                         // :86
+    const bool inside = exists && !lod && r.t_min <= tv_max;            // :89
+    const bool leaf = inside && (masks & 0x10000u);                     // :90-92
+    if (lod || leaf) {                                                  // :83-84 / :93-94
+        r.kind = lod ? 2u : 1u; r.shift = child_shift;
+        return false;
+    }
+    if (inside) {                                                       // descend, :96-111
         const float half = r.scale_f * 0.5f;                            // :87
         const float thx = half * r.tcx + cx;                            // :88
         const float thy = half * r.tcy + cy;
         const float thz = half * r.tcz + cz;
-        if (r.t_min <= tv_max) {                                        // :89
-            if (masks & 0x10000u) {                                     // :90-95
-                r.kind = 1u; r.shift = child_shift;
-                return false;
-            }
-            if (tc_max < r.h)                                           // :97-100
-                stk[(r.scale - depth_off - 1) * stride] = make_uint2(r.parent_id, f2u(r.t_max));
-            r.h = tc_max;                                               // :101
-            r.parent_id += nd.y + child_shift;                          // :103
-            r.nd = nodes[r.parent_id];
-            r.child_offset = 0u;
-            --r.scale;
-            r.scale_f = half;
-            if (thx > r.t_min) { r.child_offset ^= 1u; r.px += r.scale_f; }   // :107-109
-            if (thy > r.t_min) { r.child_offset ^= 2u; r.py += r.scale_f; }
-            if (thz > r.t_min) { r.child_offset ^= 4u; r.pz += r.scale_f; }
-            r.t_max = tv_max;                                           // :110
-            return r.scale > depth;                                     // :72 (scale < 23 holds)
-        }
+        if (tc_max < r.h)                                               // :97-100
+            stk[(r.scale - depth_off - 1) * STRIDE] = make_uint2(r.parent_id, f2u(r.t_max));
+        r.h = tc_max;                                                   // :101
+        r.parent_id += nd.y + child_shift;                              // :103
+        r.nd = nodes[r.parent_id];
+        r.child_offset = 0u;
+        --r.scale;
+        r.scale_f = half;
+        if (thx > r.t_min) { r.child_offset ^= 1u; r.px += r.scale_f; }   // :107-109
+        if (thy > r.t_min) { r.child_offset ^= 2u; r.py += r.scale_f; }
+        if (thz > r.t_min) { r.child_offset ^= 4u; r.pz += r.scale_f; }
+        r.t_max = tv_max;                                               // :110
+        return r.scale > depth;                                         // :72 (scale < 23 holds)
     }
     const uint32_t opx = f2u(r.px), opy = f2u(r.py), opz = f2u(r.pz);   // pos before the step
     uint32_t step_mask = 0u;                                            // :115-118
