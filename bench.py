@@ -113,8 +113,8 @@ def main():
     depth, W, H, spp = cfg["depth"], cfg["width"], cfg["height"], cfg["spp"]
     heights = vrc.load_terrain_heights()
     textures = vrc.load_textures()
-    nodes = vrc.build_terrain_lsvo(heights, depth)           # product host builder (csrc/vrc_builder.cpp)
-    svo = vrc.LSVO(nodes, depth, device=local_rank, textures=textures)   # LNode[] resident in HBM from here on
+    # scene built on the GPU straight into HBM (csrc/vrc_build_gpu.hip); LNode[] resident from here on
+    svo = vrc.LSVO.fromTerrain(heights, depth, device=local_rank, textures=textures)
     rc = vrc.RayCaster(svo, (W, H))
     light = vrc.reference_light(depth)
     rc.setLightPosition(light)
@@ -211,7 +211,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": cfg["label"], "rays_per_frame": rays // args.steps,
                        "loop_iterations_per_frame": steps_sum // args.steps,
-                       "camera_pitch": args.pitch, "sharding": f"{ROW_BLOCK}-row blocks round-robin over {world} GPU(s)"
+                       "camera_pitch": args.pitch, "lsvo_nodes": svo.n_nodes,
+                       "lsvo_gpu_build_ms": round(svo.build_ms, 3), "sharding": f"{ROW_BLOCK}-row blocks round-robin over {world} GPU(s)"
                        + (", RCCL all-gather of RGBA8 shards" if world > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
@@ -219,7 +220,7 @@ def main():
                          "algorithmic_bytes_per_launch": int(alg_bytes)},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, nodes, textures, cam, light)
+            out["cpu_baseline"] = cpu_baseline(cfg, svo.downloadNodes(), textures, cam, light)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

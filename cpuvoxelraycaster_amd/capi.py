@@ -58,6 +58,9 @@ SYMBOLS = {
     "vrc_build_terrain_lsvo": (_int, [_vp, _u32, C.POINTER(_vp), C.POINTER(_u64)]),
     "vrc_build_volume_lsvo": (_int, [_vp, _u32, C.POINTER(_vp), C.POINTER(_u64)]),
     "vrc_free_host": (None, [_vp]),
+    "vrc_scene_build_terrain": (_int, [_vp, _u32, _int, C.POINTER(_vp), C.POINTER(C.c_float)]),
+    "vrc_scene_build_volume": (_int, [_vp, _u32, _int, C.POINTER(_vp), C.POINTER(C.c_float)]),
+    "vrc_scene_download_nodes": (_int, [_vp, _vp]),
     "vrc_cast_rays": (_int, [_vp, _u64, _vp, _vp, _vp, _vp, _vp, _int, _vp]),
     "vrc_cast_ray": (_int, [_vp, _vp, _vp, _f32, _f32, _vp]),
     "vrc_grid_create": (_int, [_vp, _i32, _i32, _i32, _int, C.POINTER(_vp)]),

@@ -14,10 +14,10 @@
 #include "vrc_internal.h"
 
 namespace {
-
 thread_local char g_err[512] = "";
+}
 
-int fail(int code, const char* fmt, ...)
+int vrc::fail(int code, const char* fmt, ...)
 {
     va_list ap;
     va_start(ap, fmt);
@@ -25,6 +25,9 @@ int fail(int code, const char* fmt, ...)
     va_end(ap);
     return code;
 }
+using vrc::fail;
+
+namespace {
 
 #define HIP_TRY(expr)                                                                      \
     do {                                                                                   \
@@ -40,15 +43,6 @@ struct Tuning {
 } g_tuning;
 
 }  // namespace
-
-struct vrc_scene {
-    int device;
-    int cu_count;
-    void* d_nodes;
-    void* d_tex;  // 1536 bytes
-    uint64_t n_nodes;
-    uint32_t depth;
-};
 
 struct vrc_grid {
     int device;
@@ -76,7 +70,7 @@ extern "C" int vrc_device_count(void)
     return n;
 }
 
-static int require_device(int device, int* cu_count)
+int vrc::require_device(int device, int* cu_count)
 {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -92,6 +86,8 @@ static int require_device(int device, int* cu_count)
     }
     return VRC_OK;
 }
+
+using vrc::require_device;
 
 extern "C" int vrc_set_kernel(uint32_t kernel)
 {

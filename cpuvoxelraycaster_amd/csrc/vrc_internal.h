@@ -10,7 +10,21 @@
 #define VRC_KERNEL_TILE 0    // k_render_tile: tile-phased (default)
 #define VRC_KERNEL_MIXED 1   // k_render: persistent threads, mixed stages
 
+// opaque handles of include/vrc.h
+struct vrc_scene {
+    int device;
+    int cu_count;
+    void* d_nodes;
+    void* d_tex;  // 1536 bytes
+    uint64_t n_nodes;
+    uint32_t depth;
+};
+
 namespace vrc {
+
+// shared error plumbing (vrc_api.cpp)
+int fail(int code, const char* fmt, ...);
+int require_device(int device, int* cu_count);
 
 // by-value kernel argument of k_render
 struct FrameArgs {

@@ -33,6 +33,45 @@ class LSVO:
         if textures is not None:
             self.setTextures(*textures)
 
+    @classmethod
+    def _from_handle(cls, handle, depth, device, textures):
+        self = cls.__new__(cls)
+        self._h = handle
+        self.depth, self.device = depth, device
+        self.n_nodes = int(capi.load().vrc_scene_node_count(handle))
+        self.build_ms = None
+        if textures is not None:
+            self.setTextures(*textures)
+        return self
+
+    @classmethod
+    def fromTerrain(cls, height_i32, depth, device=0, textures=None):
+        """Build the LSVO of the reference's terrain generator on the GPU (main.cpp:59-88)."""
+        size = 1 << depth
+        h = np.ascontiguousarray(np.asarray(height_i32)[:size, :size], dtype=np.int32)
+        handle, ms = C.c_void_p(), C.c_float()
+        check(capi.load().vrc_scene_build_terrain(ptr(h), depth, device, C.byref(handle), C.byref(ms)))
+        self = cls._from_handle(handle, depth, device, textures)
+        self.build_ms = ms.value
+        return self
+
+    @classmethod
+    def fromVolume(cls, solid_u8, depth, device=0, textures=None):
+        """Build the LSVO of an arbitrary occupancy volume solid[x, y, z] on the GPU."""
+        size = 1 << depth
+        s = np.ascontiguousarray(solid_u8, dtype=np.uint8)
+        assert s.shape == (size, size, size)
+        handle, ms = C.c_void_p(), C.c_float()
+        check(capi.load().vrc_scene_build_volume(ptr(s), depth, device, C.byref(handle), C.byref(ms)))
+        self = cls._from_handle(handle, depth, device, textures)
+        self.build_ms = ms.value
+        return self
+
+    def downloadNodes(self):
+        out = np.zeros(self.n_nodes, capi.LNODE_DTYPE)
+        check(capi.load().vrc_scene_download_nodes(self._h, ptr(out)))
+        return out
+
     def setTextures(self, top_rgb, side_rgb):
         top = np.ascontiguousarray(top_rgb, dtype=np.uint8).reshape(-1)
         side = np.ascontiguousarray(side_rgb, dtype=np.uint8).reshape(-1)

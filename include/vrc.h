@@ -99,6 +99,15 @@ int vrc_build_volume_lsvo(const uint8_t *solid, uint32_t depth,
                           vrc_lnode **out, uint64_t *n_nodes);
 void vrc_free_host(void *p);
 
+/* The same construction on the GPU, straight into HBM (no host array): dense
+ * per-level count / rank sweeps, bit-identical output.  height / solid are host
+ * buffers laid out as above; *build_ms (optional) receives the device time of the
+ * build kernels.  vrc_scene_download_nodes copies the resident array back
+ * (vrc_scene_node_count entries). */
+int vrc_scene_build_terrain(const int32_t *height, uint32_t depth, int device, vrc_scene **out, float *build_ms);
+int vrc_scene_build_volume(const uint8_t *solid, uint32_t depth, int device, vrc_scene **out, float *build_ms);
+int vrc_scene_download_nodes(const vrc_scene *s, vrc_lnode *dst);
+
 /* ---- per-ray operator: Volumetric::castRay (volumetric.hpp:58, lsvo.hpp:33) */
 
 /* Batch form of HitPoint castRay(position, direction, ray_size_coef,
