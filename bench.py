@@ -100,9 +100,16 @@ def main():
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # one process per GPU; VRC_DIST_BACKEND=gloo (+ ranks sharing a GPU) exists only to exercise the
+    # N > 1 code path on a single-GPU box -- the real run is nccl (= RCCL over xGMI)
+    backend = os.environ.get("VRC_DIST_BACKEND", "nccl")
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     if not os.path.exists(vrc.capi.LIB_PATH):
         g.build()
     if args.tuning:
@@ -145,7 +152,13 @@ def main():
         rc.samples_to_image(stream)
         if world > 1:
             rc.packShard(ROW_BLOCK, rank, world, mine.data_ptr(), stream)
-            dist.all_gather_into_tensor(gathered, mine)       # RCCL over xGMI: RGBA8 row-block shards
+            if backend == "nccl":
+                dist.all_gather_into_tensor(gathered, mine)   # RCCL over xGMI: RGBA8 row-block shards
+            else:
+                torch.cuda.current_stream().synchronize()
+                parts = [torch.empty_like(mine) for _ in range(world)]
+                dist.all_gather(parts, mine)
+                gathered.copy_(torch.cat(parts))
             vrc.capi.check(L.vrc_unpack_shards(vrc.capi.ptr(gathered.data_ptr()), W, H, ROW_BLOCK, world,
                                                vrc.capi.ptr(full.data_ptr()), vrc.capi.ptr(stream)))
         if timed:
@@ -182,6 +195,18 @@ def main():
     else:
         kernel_ms_max = kernel_ms
 
+    verified = None
+    if world > 1 and rank == 0:
+        # not timed: the gathered frame must equal the unsharded render of the same samples
+        ref = vrc.RayCaster(svo, (W, H))
+        ref.setLightPosition(light)
+        ref.use_gi, ref.use_samples, ref.shadow_samples = bool(cfg["use_gi"]), True, 1
+        ref.frame_index = rc.frame_index - spp
+        ref.renderFrame(cam, spp=spp, stream=stream)
+        ref.samples_to_image(stream)
+        torch.cuda.synchronize()
+        verified = bool(np.array_equal(full.cpu().numpy().reshape(H, W, 4), ref.readImage(stream)))
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         # roofline of the dominant kernel (k_render), this rank's launches:
@@ -213,7 +238,8 @@ def main():
                        "loop_iterations_per_frame": steps_sum // args.steps,
                        "camera_pitch": args.pitch, "lsvo_nodes": svo.n_nodes,
                        "lsvo_gpu_build_ms": round(svo.build_ms, 3), "sharding": f"{ROW_BLOCK}-row blocks round-robin over {world} GPU(s)"
-                       + (", RCCL all-gather of RGBA8 shards" if world > 1 else "")},
+                       + (", RCCL all-gather of RGBA8 shards" if world > 1 else ""),
+                       "gathered_frame_equals_unsharded": verified},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
                          "kernel": "k_render_tile" if args.kernel == 0 else "k_render", "kernel_ms": round(kernel_ms, 4), "kernel_ms_max_rank": round(kernel_ms_max, 4),
