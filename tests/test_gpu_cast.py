@@ -141,3 +141,28 @@ def test_non_finite_rays_terminate_as_misses(terrain):
     assert_hits_equal(got, ref)
     bad = ~(np.isfinite(org).all(1) & np.isfinite(d).all(1))
     assert not got["hit"][bad].any() and not got["complexity"][bad].any()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_differential_fuzz_random_scenes(built, seed):
+    """Random occupancy volumes (depth 3..6, sparse to dense), random rays with random
+    LOD parameters: kernel and oracle must agree bit for bit on every field."""
+    import cpuvoxelraycaster_amd as vrc
+    rng = np.random.default_rng(1000 + seed)
+    depth = int(rng.integers(3, 7))
+    S = 1 << depth
+    density = float(rng.choice([0.002, 0.02, 0.1, 0.4, 0.9]))
+    vol = (rng.random((S, S, S)) < density).astype(np.uint8)
+    if seed % 3 == 0:       # structured: a few solid slabs and columns
+        vol[:] = 0
+        vol[:, S // 3, :] = 1
+        vol[S // 2, :, S // 4] = 1
+        vol[rng.integers(0, S, 30), rng.integers(0, S, 30), rng.integers(0, S, 30)] = 1
+    svo = vrc.LSVO.fromVolume(vol, depth)
+    nodes = svo.downloadNodes()
+    org, d = raygen.mixed_rays(40000, seed=seed)
+    coef = rng.choice([0.0, 0.0, 0.25, 0.5, 1.5], size=len(org)).astype(np.float32)
+    bias = rng.choice([0.0, 0.0, 0.0, 0.002, 0.05], size=len(org)).astype(np.float32)
+    got = svo.castRays(org, d, coef=coef, bias=bias)
+    ref = O.cast_rays(nodes, depth, org, d, coef=coef, bias=bias, threads=8)
+    assert_hits_equal(got, ref)
