@@ -118,10 +118,10 @@ def main():
 
     cfg = CONFIGS[args.config]
     depth, W, H, spp = cfg["depth"], cfg["width"], cfg["height"], cfg["spp"]
-    heights = vrc.load_terrain_heights()
     textures = vrc.load_textures()
-    # scene built on the GPU straight into HBM (csrc/vrc_build_gpu.hip); LNode[] resident from here on
-    svo = vrc.LSVO.fromTerrain(heights, depth, device=local_rank, textures=textures)
+    # main.cpp:59-88 on the GPU: FastNoise heights -> LSVO, straight into HBM (csrc/vrc_build_gpu.hip);
+    # the LNode[] is resident from here on
+    svo = vrc.LSVO.fromFastNoiseTerrain(depth, seed=1337, device=local_rank, textures=textures)
     rc = vrc.RayCaster(svo, (W, H))
     light = vrc.reference_light(depth)
     rc.setLightPosition(light)

@@ -61,6 +61,8 @@ SYMBOLS = {
     "vrc_scene_build_terrain": (_int, [_vp, _u32, _int, C.POINTER(_vp), C.POINTER(C.c_float)]),
     "vrc_scene_build_volume": (_int, [_vp, _u32, _int, C.POINTER(_vp), C.POINTER(C.c_float)]),
     "vrc_scene_download_nodes": (_int, [_vp, _vp]),
+    "vrc_terrain_heights": (_int, [_i32, _u32, _int, _vp]),
+    "vrc_scene_build_fastnoise_terrain": (_int, [_i32, _u32, _int, C.POINTER(_vp), C.POINTER(C.c_float)]),
     "vrc_cast_rays": (_int, [_vp, _u64, _vp, _vp, _vp, _vp, _vp, _int, _vp]),
     "vrc_cast_ray": (_int, [_vp, _vp, _vp, _f32, _f32, _vp]),
     "vrc_grid_create": (_int, [_vp, _i32, _i32, _i32, _int, C.POINTER(_vp)]),

@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <random>
 #include <vector>
 
 #include "../../include/vrc.h"
@@ -210,6 +211,143 @@ done:
 }
 
 }  // namespace
+
+// ---------------------------------------------------------------------------
+// N4: the terrain generator's noise (src/main.cpp:61-69 over the vendored
+// FastNoise v0.4.1, SimplexFractal / FBM, FN_DECIMAL = float) on the GPU, so the
+// whole chain noise -> heights -> LSVO -> frames stays in HBM.  Bit-identical to
+// the real FastNoise (tests compare with heights produced by the reference's own
+// FastNoise.cpp).  All float operations in the reference's order, no contraction.
+// ---------------------------------------------------------------------------
+namespace {
+
+struct NoiseTables {
+    uint8_t perm[512], perm12[512];
+    float F2, G2, two_G2, bounding;
+};
+
+// FastNoise::SetSeed (FastNoise.cpp:197-215) + the constants of :1270-1272 and
+// CalculateFractalBounding (:217-227, gain 0.5, 3 octaves).  Host side.
+void noise_tables(int seed, NoiseTables& t)
+{
+    std::mt19937_64 gen(seed);
+    for (int i = 0; i < 256; i++) t.perm[i] = (uint8_t)i;
+    for (int j = 0; j < 256; j++) {
+        const int rng = (int)(gen() % (256 - j));
+        const int k = rng + j;
+        const int l = t.perm[j];
+        t.perm[j] = t.perm[j + 256] = t.perm[k];
+        t.perm[k] = (uint8_t)l;
+        t.perm12[j] = t.perm12[j + 256] = (uint8_t)(t.perm[j] % 12);
+    }
+    const volatile float SQRT3 = 1.7320508075688772935274463415059f;
+    t.F2 = 0.5f * (SQRT3 - 1.0f);
+    t.G2 = (3.0f - SQRT3) / 6.0f;
+    t.two_G2 = 2.0f * t.G2;
+    float amp = 0.5f, amp_fractal = 1.0f;
+    for (int i = 1; i < 3; i++) { amp_fractal += amp; amp *= 0.5f; }
+    t.bounding = 1.0f / amp_fractal;
+}
+
+__device__ __forceinline__ int fn_fast_floor(float f) { return f >= 0 ? (int)f : (int)f - 1; }   // FastNoise.cpp:184
+
+__device__ __forceinline__ float fn_grad2(const uint8_t* perm, const uint8_t* perm12, uint32_t offset, int x, int y, float xd, float yd)
+{
+    // Index2D_12 (:244-247) + GradCoord2D (:312-317); GRAD_X / GRAD_Y (:37-48) as selects
+    const uint32_t lut = perm12[(x & 0xff) + perm[(y & 0xff) + offset]];
+    const float gx = lut >= 8u ? 0.0f : ((lut & 1u) ? -1.0f : 1.0f);
+    const float gy = lut < 4u ? ((lut & 2u) ? -1.0f : 1.0f) : (lut < 8u ? 0.0f : ((lut & 1u) ? -1.0f : 1.0f));
+    return xd * gx + yd * gy;
+}
+
+__device__ float fn_simplex2(const uint8_t* perm, const uint8_t* perm12, uint32_t offset, float x, float y, float F2, float G2, float two_G2)
+{
+    // SingleSimplex (:1274-1335)
+    float t = (x + y) * F2;
+    const int i = fn_fast_floor(x + t), j = fn_fast_floor(y + t);
+    t = (float)(i + j) * G2;
+    const float X0 = (float)i - t, Y0 = (float)j - t;
+    const float x0 = x - X0, y0 = y - Y0;
+    const int i1 = x0 > y0 ? 1 : 0, j1 = x0 > y0 ? 0 : 1;
+    const float x1 = x0 - (float)i1 + G2, y1 = y0 - (float)j1 + G2;
+    const float x2 = x0 - 1.0f + two_G2, y2 = y0 - 1.0f + two_G2;
+    float n0 = 0.0f, n1 = 0.0f, n2 = 0.0f;
+    t = 0.5f - x0 * x0 - y0 * y0;
+    if (!(t < 0)) { t *= t; n0 = t * t * fn_grad2(perm, perm12, offset, i, j, x0, y0); }
+    t = 0.5f - x1 * x1 - y1 * y1;
+    if (!(t < 0)) { t *= t; n1 = t * t * fn_grad2(perm, perm12, offset, i + i1, j + j1, x1, y1); }
+    t = 0.5f - x2 * x2 - y2 * y2;
+    if (!(t < 0)) { t *= t; n2 = t * t * fn_grad2(perm, perm12, offset, i + 1, j + 1, x2, y2); }
+    return 70.0f * (n0 + n1 + n2);
+}
+
+__global__ void k_terrain_heights(NoiseTables tab, uint32_t S, int32_t* __restrict__ height)
+{
+    __shared__ uint8_t perm[512], perm12[512];
+    for (uint32_t i = threadIdx.x; i < 512u; i += blockDim.x) { perm[i] = tab.perm[i]; perm12[i] = tab.perm12[i]; }
+    __syncthreads();
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= S * S) return;
+    const uint32_t x = idx / S, z = idx % S;
+    // GetNoise(0.75 x, 0.75 z): frequency 0.01, FBM over 3 octaves, lacunarity 2, gain 0.5 (:410-447, :1175-1207)
+    float fx = (0.75f * (float)x) * 0.01f, fy = (0.75f * (float)z) * 0.01f;
+    float sum = fn_simplex2(perm, perm12, perm[0], fx, fy, tab.F2, tab.G2, tab.two_G2);
+    float amp = 1.0f;
+    for (int o = 1; o < 3; ++o) {
+        fx *= 2.0f; fy *= 2.0f;
+        amp *= 0.5f;
+        sum += fn_simplex2(perm, perm12, perm[o], fx, fy, tab.F2, tab.G2, tab.two_G2) * amp;
+    }
+    const float noise = sum * tab.bounding;
+    height[idx] = (int32_t)(64.0f * noise + 32.0f);                              // main.cpp:69
+}
+
+}  // namespace
+
+extern "C" int vrc_terrain_heights(int32_t seed, uint32_t size, int device, int32_t* height_host)
+{
+    if (!height_host || size == 0 || size > 4096) return vrc::fail(VRC_ERR_INVALID, "vrc_terrain_heights: bad argument");
+    int rc = vrc::require_device(device, nullptr);
+    if (rc) return rc;
+    NoiseTables tab;
+    noise_tables(seed, tab);
+    int32_t* d_h = nullptr;
+    hipError_t e = hipMalloc((void**)&d_h, (size_t)size * size * 4);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_terrain_heights, grid_for((uint64_t)size * size), dim3(256), 0, nullptr, tab, size, d_h);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(height_host, d_h, (size_t)size * size * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(d_h);
+    if (e != hipSuccess) return vrc::fail(e == hipErrorOutOfMemory ? VRC_ERR_OOM : VRC_ERR_HIP, "vrc_terrain_heights: %s", hipGetErrorString(e));
+    return VRC_OK;
+}
+
+// main.cpp:59-88 end to end on the device: noise -> column limits -> LSVO.
+extern "C" int vrc_scene_build_fastnoise_terrain(int32_t seed, uint32_t depth, int device, vrc_scene** out, float* build_ms)
+{
+    if (!out) return vrc::fail(VRC_ERR_INVALID, "vrc_scene_build_fastnoise_terrain: null argument");
+    if (depth < 2 || depth > 10) return vrc::fail(VRC_ERR_INVALID, "vrc_scene_build_fastnoise_terrain: depth %u not in [2,10]", depth);
+    int cus = 0;
+    int rc = vrc::require_device(device, &cus);
+    if (rc) return rc;
+    const uint32_t S = 1u << depth;
+    NoiseTables tab;
+    noise_tables(seed, tab);
+    int32_t *d_h = nullptr, *d_lim = nullptr;
+    hipError_t e = hipMalloc((void**)&d_h, (size_t)S * S * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_lim, (size_t)S * S * 4);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_terrain_heights, grid_for((uint64_t)S * S), dim3(256), 0, nullptr, tab, S, d_h);
+        hipLaunchKernelGGL(k_terrain_lim, grid_for((uint64_t)S * S), dim3(256), 0, nullptr, d_h, d_lim, S);
+        e = hipGetLastError();
+    }
+    if (e != hipSuccess) rc = vrc::fail(e == hipErrorOutOfMemory ? VRC_ERR_OOM : VRC_ERR_HIP, "vrc_scene_build_fastnoise_terrain: %s", hipGetErrorString(e));
+    else rc = build_on_device(TerrainVox{d_lim, S}, depth, device, cus, out, build_ms);
+    (void)hipFree(d_h);
+    (void)hipFree(d_lim);
+    return rc;
+}
 
 extern "C" int vrc_scene_build_terrain(const int32_t* height, uint32_t depth, int device, vrc_scene** out, float* build_ms)
 {

@@ -56,6 +56,15 @@ class LSVO:
         return self
 
     @classmethod
+    def fromFastNoiseTerrain(cls, depth, seed=1337, device=0, textures=None):
+        """main.cpp:59-88 end to end on the GPU: FastNoise heights -> LSVO."""
+        handle, ms = C.c_void_p(), C.c_float()
+        check(capi.load().vrc_scene_build_fastnoise_terrain(seed, depth, device, C.byref(handle), C.byref(ms)))
+        self = cls._from_handle(handle, depth, device, textures)
+        self.build_ms = ms.value
+        return self
+
+    @classmethod
     def fromVolume(cls, solid_u8, depth, device=0, textures=None):
         """Build the LSVO of an arbitrary occupancy volume solid[x, y, z] on the GPU."""
         size = 1 << depth

@@ -108,6 +108,14 @@ int vrc_scene_build_terrain(const int32_t *height, uint32_t depth, int device, v
 int vrc_scene_build_volume(const uint8_t *solid, uint32_t depth, int device, vrc_scene **out, float *build_ms);
 int vrc_scene_download_nodes(const vrc_scene *s, vrc_lnode *dst);
 
+/* The scene generator's noise on the GPU: height[x*size + z] =
+ * int32(64 * noise(0.75x, 0.75z) + 32) with the reference's FastNoise settings
+ * (SimplexFractal FBM, 3 octaves, frequency 0.01; seed 1337 in main.cpp:61),
+ * bit-identical to lib/fastnoise.  vrc_scene_build_fastnoise_terrain runs
+ * main.cpp:59-88 end to end on the device: noise -> heights -> LSVO in HBM. */
+int vrc_terrain_heights(int32_t seed, uint32_t size, int device, int32_t *height_host);
+int vrc_scene_build_fastnoise_terrain(int32_t seed, uint32_t depth, int device, vrc_scene **out, float *build_ms);
+
 /* ---- per-ray operator: Volumetric::castRay (volumetric.hpp:58, lsvo.hpp:33) */
 
 /* Batch form of HitPoint castRay(position, direction, ray_size_coef,

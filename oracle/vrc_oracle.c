@@ -192,6 +192,118 @@ uint64_t orc_svo_compile(const orc_svo *s, orc_lnode **out)
 }
 
 /* ------------------------------------------------------------------------- */
+/* N4: terrain heights = FastNoise SimplexFractal, as src/main.cpp:61-69 calls it */
+/* (lib/fastnoise/FastNoise.cpp, v0.4.1, FN_DECIMAL = float).  This part of the  */
+/* oracle IS pinned by reference execution: tests compare it with heights from   */
+/* the real FastNoise compiled from /root/reference (oracle/_ref).               */
+/* ------------------------------------------------------------------------- */
+
+/* std::mt19937_64 (ISO C++ [rand.predef]): FastNoise::SetSeed, FastNoise.cpp:197-215 */
+typedef struct { uint64_t mt[312]; int idx; } mt64;
+static void mt64_seed(mt64 *g, uint64_t seed)
+{
+    g->mt[0] = seed;
+    for (int i = 1; i < 312; i++) g->mt[i] = 6364136223846793005ULL * (g->mt[i - 1] ^ (g->mt[i - 1] >> 62)) + (uint64_t)i;
+    g->idx = 312;
+}
+static uint64_t mt64_next(mt64 *g)
+{
+    if (g->idx >= 312) {
+        for (int i = 0; i < 312; i++) {
+            const uint64_t x = (g->mt[i] & 0xFFFFFFFF80000000ULL) | (g->mt[(i + 1) % 312] & 0x7FFFFFFFULL);
+            g->mt[i] = g->mt[(i + 156) % 312] ^ (x >> 1) ^ ((x & 1ULL) ? 0xB5026F5AA96619E9ULL : 0ULL);
+        }
+        g->idx = 0;
+    }
+    uint64_t y = g->mt[g->idx++];
+    y ^= (y >> 29) & 0x5555555555555555ULL;
+    y ^= (y << 17) & 0x71D67FFFEDA60000ULL;
+    y ^= (y << 37) & 0xFFF7EEE000000000ULL;
+    y ^= (y >> 43);
+    return y;
+}
+
+typedef struct { uint8_t perm[512], perm12[512]; float F2, G2, bounding; } fnoise;
+
+static void fnoise_init(fnoise *n, int seed)
+{
+    mt64 gen;
+    mt64_seed(&gen, (uint64_t)(int64_t)seed);               /* std::mt19937_64 gen(seed), :201 */
+    for (int i = 0; i < 256; i++) n->perm[i] = (uint8_t)i;
+    for (int j = 0; j < 256; j++) {                         /* :206-214 */
+        const int rng = (int)(mt64_next(&gen) % (uint64_t)(256 - j));
+        const int k = rng + j;
+        const int l = n->perm[j];
+        n->perm[j] = n->perm[j + 256] = n->perm[k];
+        n->perm[k] = (uint8_t)l;
+        n->perm12[j] = n->perm12[j + 256] = (uint8_t)(n->perm[j] % 12);
+    }
+    const float SQRT3 = 1.7320508075688772935274463415059f; /* :1270-1272 */
+    n->F2 = 0.5f * (SQRT3 - 1.0f);
+    n->G2 = (3.0f - SQRT3) / 6.0f;
+    float amp = 0.5f, ampFractal = 1.0f;                    /* CalculateFractalBounding :217-227, gain .5, 3 octaves */
+    for (int i = 1; i < 3; i++) { ampFractal += amp; amp *= 0.5f; }
+    n->bounding = 1.0f / ampFractal;
+}
+
+static const float FN_GRAD_X[12] = { 1, -1, 1, -1, 1, -1, 1, -1, 0, 0, 0, 0 };   /* FastNoise.cpp:37-48 */
+static const float FN_GRAD_Y[12] = { 1, 1, -1, -1, 0, 0, 0, 0, 1, -1, 1, -1 };
+
+static inline int fn_fast_floor(float f) { return f >= 0 ? (int)f : (int)f - 1; } /* :184 */
+
+static float fn_grad2(const fnoise *n, uint8_t offset, int x, int y, float xd, float yd)  /* :244-247,:312-317 */
+{
+    const uint8_t lut = n->perm12[(x & 0xff) + n->perm[(y & 0xff) + offset]];
+    return xd * FN_GRAD_X[lut] + yd * FN_GRAD_Y[lut];
+}
+
+static float fn_simplex2(const fnoise *n, uint8_t offset, float x, float y)      /* :1274-1335 */
+{
+    float t = (x + y) * n->F2;
+    const int i = fn_fast_floor(x + t), j = fn_fast_floor(y + t);
+    t = (float)(i + j) * n->G2;
+    const float X0 = (float)i - t, Y0 = (float)j - t;
+    const float x0 = x - X0, y0 = y - Y0;
+    int i1, j1;
+    if (x0 > y0) { i1 = 1; j1 = 0; } else { i1 = 0; j1 = 1; }
+    const float x1 = x0 - (float)i1 + n->G2, y1 = y0 - (float)j1 + n->G2;
+    const float two_g2 = 2.0f * n->G2;
+    const float x2 = x0 - 1.0f + two_g2, y2 = y0 - 1.0f + two_g2;
+    float n0, n1, n2;
+    t = 0.5f - x0 * x0 - y0 * y0;
+    if (t < 0) n0 = 0; else { t *= t; n0 = t * t * fn_grad2(n, offset, i, j, x0, y0); }
+    t = 0.5f - x1 * x1 - y1 * y1;
+    if (t < 0) n1 = 0; else { t *= t; n1 = t * t * fn_grad2(n, offset, i + i1, j + j1, x1, y1); }
+    t = 0.5f - x2 * x2 - y2 * y2;
+    if (t < 0) n2 = 0; else { t *= t; n2 = t * t * fn_grad2(n, offset, i + 1, j + 1, x2, y2); }
+    return 70.0f * (n0 + n1 + n2);
+}
+
+/* GetNoise -> GetSimplexFractal -> SingleSimplexFractalFBM (:410-447,:1175-1207): frequency .01, lacunarity 2 */
+static float fn_get_noise(const fnoise *n, float x, float y)
+{
+    x *= 0.01f; y *= 0.01f;
+    float sum = fn_simplex2(n, n->perm[0], x, y);
+    float amp = 1.0f;
+    for (int i = 1; i < 3; i++) {
+        x *= 2.0f; y *= 2.0f;
+        amp *= 0.5f;
+        sum += fn_simplex2(n, n->perm[i], x, y) * amp;
+    }
+    return sum * n->bounding;
+}
+
+/* main.cpp:61-69: FastNoise myNoise (seed 1337); height = int32(64 * GetNoise(.75 x, .75 z) + 32) */
+void orc_terrain_heights(int32_t size, int32_t seed, int32_t *height)
+{
+    fnoise n;
+    fnoise_init(&n, seed);
+    for (uint32_t x = 0; x < (uint32_t)size; x++)
+        for (uint32_t z = 0; z < (uint32_t)size; z++)
+            height[(int64_t)x * size + z] = (int32_t)(64.0f * fn_get_noise(&n, (float)(0.75f * (float)x), (float)(0.75f * (float)z)) + 32.0f);
+}
+
+/* ------------------------------------------------------------------------- */
 /* T1: LSVO<N>::castRay (lsvo.hpp:33-172)                                    */
 /* ------------------------------------------------------------------------- */
 

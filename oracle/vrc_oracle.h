@@ -11,8 +11,11 @@
  * its traversal / shading headers need GLM and SFML, which this image lacks,
  * so they cannot be compiled here without stand-in headers (not allowed).
  * What IS pinned:
- *   - terrain heights come from the real vendored FastNoise compiled from
- *     /root/reference (oracle/_ref, see oracle/Makefile, tools/make_golden.py);
+ *   - terrain heights: the restated SimplexFractal noise (orc_terrain_heights)
+ *     equals, for all 1024 x 1024 columns, the output of the real vendored
+ *     FastNoise compiled from /root/reference (oracle/_ref, oracle/Makefile,
+ *     tools/make_golden.py -> tests/golden/terrain_height_1024.npz) -- this row
+ *     is pinned by reference execution;
  *   - the restated builder + traversal reproduce the statistics SURVEY.md
  *     App. B measured on the unmodified reference (node count 10 528 393 at
  *     512^3, first nodes, level histogram, per-pose hit counts, mean / max
@@ -66,6 +69,10 @@ void orc_svo_fill_terrain(orc_svo *s, const int32_t *height);
 /* returns node count; *out is malloc'd (free with orc_free). */
 uint64_t orc_svo_compile(const orc_svo *s, orc_lnode **out);
 void orc_free(void *p);
+
+/* ---- N4: terrain heights (main.cpp:61-69 over lib/fastnoise SimplexFractal);
+ * height[x*size + z]; pinned against the real FastNoise build (oracle/_ref). ---- */
+void orc_terrain_heights(int32_t size, int32_t seed, int32_t *height);
 
 /* ---- T1: LSVO<N>::castRay (lsvo.hpp:33-172) ---- */
 void orc_cast_ray(const orc_lnode *nodes, uint32_t depth,

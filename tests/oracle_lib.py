@@ -81,6 +81,7 @@ def lib():
     L.orc_render_frame.argtypes = [vp, u32, vp, vp, C.POINTER(Camera), C.POINTER(FrameParams),
                                    vp, vp, vp, C.POINTER(FrameStats), C.c_int]
     L.orc_samples_to_image.argtypes = [vp, u32, u32, vp]
+    L.orc_terrain_heights.argtypes = [i32, i32, vp]
     _lib = L
     return L
 
@@ -116,6 +117,12 @@ def compile_terrain(depth, height_i32):
     L.orc_free(out)
     L.orc_svo_free(s)
     return arr
+
+
+def terrain_heights(size, seed=1337):
+    h = np.zeros((size, size), np.int32)
+    lib().orc_terrain_heights(size, seed, _ptr(h))
+    return h
 
 
 def cast_rays(nodes, depth, org, dir_, coef=None, bias=None, threads=1):

@@ -58,3 +58,23 @@ def test_builder_1024_properties(built, heights):
     assert int((n["child_mask"] != 0).sum()) * 8 + 1 == svo.n_nodes
     again = vrc.LSVO.fromTerrain(heights, 10).downloadNodes()
     assert np.array_equal(n.view(np.uint64), again.view(np.uint64))
+
+
+def test_gpu_noise_matches_real_fastnoise(built, heights):
+    """N4, pinned by reference execution: the GPU terrain-height kernel against the
+    fixture produced by the reference's own FastNoise.cpp (tools/make_golden.py)."""
+    import ctypes as C
+    import cpuvoxelraycaster_amd as vrc
+    h = np.zeros((1024, 1024), np.int32)
+    vrc.capi.check(vrc.capi.load().vrc_terrain_heights(1337, 1024, 0, vrc.capi.ptr(h)))
+    assert np.array_equal(h, heights)
+    other = np.zeros((64, 64), np.int32)
+    vrc.capi.check(vrc.capi.load().vrc_terrain_heights(7, 64, 0, vrc.capi.ptr(other)))
+    assert np.array_equal(other, O.terrain_heights(64, seed=7)) and not np.array_equal(other, heights[:64, :64])
+
+
+def test_fastnoise_scene_equals_fixture_scene(built, heights):
+    import cpuvoxelraycaster_amd as vrc
+    a = vrc.LSVO.fromFastNoiseTerrain(9).downloadNodes()
+    b = vrc.LSVO.fromTerrain(heights, 9).downloadNodes()
+    assert np.array_equal(a.view(np.uint64), b.view(np.uint64)) and len(a) == 10528393

@@ -141,3 +141,23 @@ def test_scene_cameras_are_in_free_space(heights, textures):
 def test_nan_ray_is_a_miss(nodes9):
     h = O.cast_rays(nodes9, 9, np.array([[1.5, 1.4, 1.5]], np.float32), np.array([[np.nan, 0.5, 0.5]], np.float32))[0]
     assert h["hit"] == 0 and h["complexity"] == 0
+
+
+def test_noise_restatement_equals_real_fastnoise(heights):
+    """The one place where the oracle is pinned by running the reference itself: the
+    restated SimplexFractal terrain heights equal, for all 1024 x 1024 columns, the
+    fixture generated by the reference's own lib/fastnoise/FastNoise.cpp."""
+    assert np.array_equal(O.terrain_heights(1024), heights)
+
+
+def test_noise_restatement_against_live_reference_build(heights):
+    """Where /root/reference is mounted, also compare with oracle/_ref directly."""
+    import ctypes as C
+    import os
+    ref = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libref_fastnoise.so")
+    if not os.path.exists(ref):
+        pytest.skip("oracle/_ref not built (reference not mounted)")
+    lib = C.CDLL(ref)
+    h = np.zeros((300, 300), np.int32)
+    lib.ref_terrain_heights(C.c_int32(300), h.ctypes.data_as(C.c_void_p))
+    assert np.array_equal(h, O.terrain_heights(300)) and np.array_equal(h, heights[:300, :300])
