@@ -29,7 +29,8 @@ CONFIGS = {
     "c2": dict(depth=8, width=1280, height=720, spp=1, use_gi=0, aperture=0.0,
                label="256^3 LSVO terrain, 1280x720, primary + 1 shadow ray"),
     "c3": dict(depth=9, width=1920, height=1080, spp=4, use_gi=1, aperture=0.0,
-               label="512^3 LSVO terrain (FastNoise fixture), 1920x1080, 4 spp GI (1 indirect bounce), shadow_samples=1"),
+               label="512^3 LSVO terrain (FastNoise seed 1337, generated and built on the GPU), 1920x1080, 4 spp GI "
+                     "(1 indirect bounce), shadow_samples=1"),
     "c3nogi": dict(depth=9, width=1920, height=1080, spp=4, use_gi=0, aperture=0.0,
                    label="512^3 LSVO terrain, 1920x1080, 4 spp, primary + 1 shadow ray (no GI)"),
     "c4": dict(depth=9, width=1920, height=1080, spp=4, use_gi=1, aperture=0.5,
@@ -133,11 +134,24 @@ def main():
 
     shard_bytes = L.vrc_shard_bytes(W, H, ROW_BLOCK, world)
     if world > 1:
-        mine = torch.empty(shard_bytes, dtype=torch.uint8, device="cuda")
-        gathered = torch.empty(world * shard_bytes, dtype=torch.uint8, device="cuda")
+        # double-buffered so the all-gather of frame i (RCCL's stream) overlaps the render of frame i+1
+        mine = [torch.empty(shard_bytes, dtype=torch.uint8, device="cuda") for _ in range(2)]
+        gathered = [torch.empty(world * shard_bytes, dtype=torch.uint8, device="cuda") for _ in range(2)]
         full = torch.empty(H * W * 4, dtype=torch.uint8, device="cuda")
 
     ev_pairs = []
+    state = {"i": 0, "pending": None}
+
+    def finish_gather():
+        """wait for the outstanding all-gather and scatter it into the full frame"""
+        if state["pending"] is None:
+            return
+        work, slot = state["pending"]
+        if work is not None:
+            work.wait()                                        # current stream waits for the collective
+        vrc.capi.check(L.vrc_unpack_shards(vrc.capi.ptr(gathered[slot].data_ptr()), W, H, ROW_BLOCK, world,
+                                           vrc.capi.ptr(full.data_ptr()), vrc.capi.ptr(stream)))
+        state["pending"] = None
 
     def step(timed):
         rc.resetSamples(stream)
@@ -151,21 +165,27 @@ def main():
         e1.record()
         rc.samples_to_image(stream)
         if world > 1:
-            rc.packShard(ROW_BLOCK, rank, world, mine.data_ptr(), stream)
+            slot = state["i"] % 2
+            rc.packShard(ROW_BLOCK, rank, world, mine[slot].data_ptr(), stream)
             if backend == "nccl":
-                dist.all_gather_into_tensor(gathered, mine)   # RCCL over xGMI: RGBA8 row-block shards
+                # RCCL over xGMI: RGBA8 row-block shards; enqueued behind the pack, runs beside the next render
+                work = dist.all_gather_into_tensor(gathered[slot], mine[slot], async_op=True)
             else:
                 torch.cuda.current_stream().synchronize()
-                parts = [torch.empty_like(mine) for _ in range(world)]
-                dist.all_gather(parts, mine)
-                gathered.copy_(torch.cat(parts))
-            vrc.capi.check(L.vrc_unpack_shards(vrc.capi.ptr(gathered.data_ptr()), W, H, ROW_BLOCK, world,
-                                               vrc.capi.ptr(full.data_ptr()), vrc.capi.ptr(stream)))
+                parts = [torch.empty_like(mine[slot]) for _ in range(world)]
+                dist.all_gather(parts, mine[slot])
+                gathered[slot].copy_(torch.cat(parts))
+                work = None
+            finish_gather()                                    # previous frame's gather -> full frame
+            state["pending"] = (work, slot)
+            state["i"] += 1
         if timed:
             ev_pairs.append((e0, e1))
 
     for _ in range(args.warmup):
         step(False)
+    if world > 1:
+        finish_gather()
     rc.stats(reset=True, stream=stream)
     if world > 1:
         dist.barrier()
@@ -173,6 +193,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
+    if world > 1:
+        finish_gather()                                        # the last frame's gather is inside the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -221,3 +221,14 @@ def test_camera_inside_solid_terminates(scene, textures):
     assert np.array_equal(rc.readAccum(), oacc)
     s = rc.stats()
     assert (s.rays, s.sum_complexity) == (st.rays, st.sum_complexity)
+
+
+@pytest.mark.parametrize("spp", [5, 9])
+def test_many_samples_per_call(scene, textures, spp):
+    """spp above the tile kernel's 4-samples-per-pass pool: full passes + a partial one."""
+    run_pair(scene, textures, 7, 96, 56, -0.5, spp=spp, use_gi=1)
+
+
+def test_temporal_blend_multiple_samples_per_call(scene, textures):
+    """Non-sample mode with spp > 1: the 0.4/0.6 blend is applied once per sample, in order."""
+    run_pair(scene, textures, 7, 96, 56, -0.5, spp=3, frames=2, use_gi=1, use_samples=0)
