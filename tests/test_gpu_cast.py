@@ -166,3 +166,60 @@ def test_differential_fuzz_random_scenes(built, seed):
     got = svo.castRays(org, d, coef=coef, bias=bias)
     ref = O.cast_rays(nodes, depth, org, d, coef=coef, bias=bias, threads=8)
     assert_hits_equal(got, ref)
+
+
+def test_maximum_depth_scene(built):
+    """VRC_MAX_DEPTH = 11 (2048^3): a sparse scene built by the oracle's setCell + compileSVO."""
+    import cpuvoxelraycaster_amd as vrc
+    depth, S = 11, 2048
+    rng = np.random.default_rng(42)
+    vox = rng.integers(0, S, (300, 3))
+    vox = np.concatenate([vox, [[0, 0, 0], [S - 1, S - 1, S - 1], [1024, 1024, 1024], [1023, 1023, 1023]]])
+    nodes = O.compile_voxels(depth, vox)
+    svo = vrc.LSVO(nodes, depth)
+    # rays aimed at the voxels from random origins, plus random rays.  The walk addresses child
+    # slots with inverted position bits (lsvo.hpp:79), i.e. it sees the scene point-reflected
+    # through the cube centre: voxel v appears at S-1-v.
+    tgt = (S - 1 - vox[rng.integers(0, len(vox), 20000)] + 0.5) / S + 1.0
+    org = rng.uniform(1.0, 2.0, tgt.shape)
+    d = tgt - org
+    o2, d2 = raygen.mixed_rays(20000, seed=9)
+    org = np.concatenate([org, o2]).astype(np.float32)
+    d = np.concatenate([d, d2]).astype(np.float32)
+    got = svo.castRays(org, d)
+    ref = O.cast_rays(nodes, depth, org, d, threads=8)
+    assert_hits_equal(got, ref)
+    assert (got["hit"] != 0).sum() > 1000
+    # frame kernel at maximum depth: LDS stack of 10 slots
+    rc = vrc.RayCaster(svo, (64, 48))
+    rc.setLightPosition((0.6, -0.9, 0.4))
+    rc.use_gi = rc.use_samples = True
+    rc.shadow_samples = 1
+    cam = vrc.make_camera((1024.0, 900.0, 1000.0), vrc.make_rotation(0.3, -0.4))
+    rc.renderFrame(cam, spp=2)
+    ocam = O.make_camera(tuple(cam.position), tuple(cam.rot), 1.0, 0.0, 1.0)
+    top = side = np.full(768, 255, np.uint8)
+    acc = None
+    for s in range(2):
+        p = O.make_params(64, 48, (0.6, -0.9, 0.4), use_gi=1, use_samples=1, shadow_samples=1, frame_index=s)
+        _, acc, _, _ = O.render_frame(nodes, depth, top, side, ocam, p, accum=acc, threads=4)
+    assert np.array_equal(rc.readAccum(), acc)
+
+
+def test_argument_validation(built):
+    import ctypes as C
+    import cpuvoxelraycaster_amd as vrc
+    L = vrc.capi.load()
+    nodes = np.zeros(9, vrc.LNODE_DTYPE)
+    h = C.c_void_p()
+    assert L.vrc_scene_create(vrc.capi.ptr(nodes), 9, 12, 0, C.byref(h)) == -1      # depth > VRC_MAX_DEPTH
+    assert L.vrc_scene_create(vrc.capi.ptr(nodes), 0, 3, 0, C.byref(h)) == -1       # empty
+    assert L.vrc_scene_create(vrc.capi.ptr(nodes), 9, 3, 99, C.byref(h)) == -1      # no such device
+    assert b"device" in L.vrc_last_error()
+    svo = vrc.LSVO(nodes, 3)
+    rc = vrc.RayCaster(svo, (8, 8))
+    rc.gi_bounces = 3
+    with pytest.raises(vrc.VrcError):
+        rc.renderFrame(vrc.make_camera((4, 4, 4), vrc.make_rotation(0, 0)))
+    with pytest.raises(vrc.VrcError):
+        vrc.RayCaster(svo, (0, 8))
