@@ -148,7 +148,10 @@ __device__ __forceinline__ bool ray_setup(Ray& r, const uint2* __restrict__ node
 // lane's column of the LDS stack, STRIDE = lanes per row, so slot s lives at
 // stk[s*stride]; slots are (scale - DEPTH_OFFSET - 1) in [0, depth-2].
 // Returns the loop condition for the next iteration.
-template <int STRIDE>
+// LOD = false: the caller guarantees ray_size_coef == 0 and ray_size_bias == 0 (primary and
+// shadow rays, raycaster.hpp:131,153).  Then tc_max * 0 + 0 is 0 (or NaN for an infinite
+// tc_max) and never >= scale_f > 0, so the LOD test of :82 cannot fire and is not evaluated.
+template <int STRIDE, bool LOD = true>
 __device__ __forceinline__ bool ray_step(Ray& r, const uint2* __restrict__ nodes, uint2* stk,
                                          int depth, float coef, float bias)
 {
@@ -165,7 +168,7 @@ __device__ __forceinline__ bool ray_step(Ray& r, const uint2* __restrict__ nodes
     // The nested tests of :81-95 as flat predicates (same comparisons, same order of
     // evaluation where it matters: every operand is a plain value, no side effects).
     const bool exists = (masks & 0x100u) && r.t_min <= r.t_max;        // :81
-    const bool lod = exists && (tc_max * coef + bias >= r.scale_f);     // :82
+    const bool lod = LOD && exists && (tc_max * coef + bias >= r.scale_f);   // :82
     const float tv_max = tmin(r.t_max, tc_max);                         // :86
     const bool inside = exists && !lod && r.t_min <= tv_max;            // :89
     const bool leaf = inside && (masks & 0x10000u);                     // :90-92

@@ -560,7 +560,7 @@ k_render_tile(const FrameArgs a)
                     float oz = (a.cam.position[2] + wz) * inv_size + 1.0f;
                     Ray r;
                     bool active = ray_setup(r, nodes, ox, oy, oz, dx, dy, dz);
-                    while (active) active = ray_step<VRC_RENDER_BLOCK>(r, nodes, stk, depth, 0.0f, 0.0f);
+                    while (active) active = ray_step<VRC_RENDER_BLOCK, false>(r, nodes, stk, depth, 0.0f, 0.0f);
                     n_rays += 1u; n_steps += r.complexity;
                     ray_finish(r, depth, ox, oy, oz, dx, dy, dz, h);               // raycaster.hpp:131
                     if (a.prim && sample == 0u) {
@@ -587,7 +587,7 @@ k_render_tile(const FrameArgs a)
                             normalize3(dx, dy, dz);
                             const float lit = smax(0.0f, dot3(dx, dy, dz, h.nx, h.ny, h.nz));   // :156
                             active = ray_setup(r, nodes, ox, oy, oz, dx, dy, dz);
-                            while (active) active = ray_step<VRC_RENDER_BLOCK>(r, nodes, stk, depth, 0.0f, 0.0f);
+                            while (active) active = ray_step<VRC_RENDER_BLOCK, false>(r, nodes, stk, depth, 0.0f, 0.0f);
                             n_rays += 1u; n_steps += r.complexity;
                             if (!r.kind) light_intensity = lit;                              // :155-157
                         }
