@@ -577,6 +577,12 @@ uint64_t orc_xorshf96(void)
     return xs_z;
 }
 
+/* n consecutive outputs of the serial stream (bulk form for the tests) */
+void orc_xorshf96_fill(uint64_t n, uint64_t *out)
+{
+    for (uint64_t i = 0; i < n; i++) out[i] = orc_xorshf96();
+}
+
 /* The parallel replacement for the racy global stream:
  * a counter-based generator keyed by (seed, frame/sample, global pixel, draw#).
  * Integer-only so CPU and GPU agree bit for bit.  Not from the reference. */

@@ -77,6 +77,7 @@ def lib():
     L.orc_get_rand_counter.restype = f32
     L.orc_get_rand_counter.argtypes = [u32, f32, f32]
     L.orc_xorshf96.restype = u64
+    L.orc_xorshf96_fill.argtypes = [u64, vp]
     L.orc_make_rotation.argtypes = [f32, f32, vp]
     L.orc_render_frame.argtypes = [vp, u32, vp, vp, C.POINTER(Camera), C.POINTER(FrameParams),
                                    vp, vp, vp, C.POINTER(FrameStats), C.c_int]
@@ -117,6 +118,20 @@ def compile_terrain(depth, height_i32):
     L.orc_free(out)
     L.orc_svo_free(s)
     return arr
+
+
+def xorshf96_draws(n):
+    """next n outputs of the reference's global xorshf96 stream (utils.cpp:11-25)"""
+    out = np.zeros(n, np.uint64)
+    lib().orc_xorshf96_fill(n, _ptr(out))
+    return out
+
+
+def get_rand(z, mn, mx):
+    """getRand (utils.cpp:77-81) applied to raw xorshf96 outputs"""
+    f = np.float32
+    rv = (z % np.uint64(100)).astype(f) / f(100.0)
+    return (f(mn) + (f(mx) - f(mn)) * rv).astype(f)
 
 
 def terrain_heights(size, seed=1337):

@@ -161,3 +161,63 @@ def test_noise_restatement_against_live_reference_build(heights):
     h = np.zeros((300, 300), np.int32)
     lib.ref_terrain_heights(C.c_int32(300), h.ctypes.data_as(C.c_void_p))
     assert np.array_equal(h, O.terrain_heights(300)) and np.array_equal(h, heights[:300, :300])
+
+
+def test_reference_probe_sequence_random_and_gi_rays(nodes9):
+    """SURVEY App. B's instrumented run of the unmodified reference, replayed draw for
+    draw with the restated xorshf96 stream (utils.cpp:11-25, LP64): after 960x540
+    getRay calls (2 draws each) it cast 200 000 random rays with origins in [0,3)^3
+    (5 025 hits), 100 000 axis rays (2 draws each), and then, on every second pixel of
+    the pitch -0.5 frame, one GI ray (coef 0.5) per primary hit: 128 568 primary hits,
+    116 671 GI hits = 77 971 LOD cut-offs (per-scale histogram below) + 38 700 leaf hits.
+    Pins the RNG restatement, getRand's quantisation, the GI ray construction
+    (raycaster.hpp:171-194), the LOD cut (lsvo.hpp:82-85) and walks from outside the cube."""
+    f = np.float32
+    O.lib().orc_xorshf96_reset()
+    O.xorshf96_draws(518400 * 2)
+    z = O.xorshf96_draws(200000 * 6).reshape(200000, 6)
+    org = O.get_rand(z[:, 0:3], 0, 3)
+    dd = (O.get_rand(z[:, 3:6], -1, 1) + f(0.003)).astype(f)
+    inv = (f(1) / np.sqrt((dd[:, 0] * dd[:, 0] + dd[:, 1] * dd[:, 1]) + dd[:, 2] * dd[:, 2])).astype(f)
+    h = O.cast_rays(nodes9, 9, org, (dd * inv[:, None]).astype(f), threads=8)
+    assert int((h["hit"] != 0).sum()) == 5025
+    O.xorshf96_draws(100000 * 2)
+    W, H = 960, 540
+    X, Y = np.meshgrid(np.arange(0, W, 2), np.arange(0, H, 2), indexing="ij")      # x outer, y inner
+    X, Y = X.reshape(-1).astype(f), Y.reshape(-1).astype(f)
+    v = np.stack([X / f(H) - f(W) / f(H) * f(0.5), Y / f(H) - f(0.5), np.ones_like(X)], 1).astype(f)
+
+    def normalize(a):
+        i = (f(1) / np.sqrt((a[:, 0] * a[:, 0] + a[:, 1] * a[:, 1]) + a[:, 2] * a[:, 2])).astype(f)
+        return (a * i[:, None]).astype(f)
+
+    r = normalize(normalize(v))            # focal_length 1, aperture 0 (camera_controller.hpp:39-42)
+    m = O.make_rotation(0.0, -0.5)
+    d = np.stack([(m[0] * r[:, 0] + m[1] * r[:, 1]) + m[2] * r[:, 2], (m[3] * r[:, 0] + m[4] * r[:, 1]) + m[5] * r[:, 2],
+                  (m[6] * r[:, 0] + m[7] * r[:, 1]) + m[8] * r[:, 2]], 1).astype(f)
+    o = np.tile(np.array([256, 200, 256], f) * f(1 / 512) + f(1), (len(d), 1)).astype(f)
+    prim = O.cast_rays(nodes9, 9, o, d, threads=8)
+    hit = prim["hit"] != 0
+    assert int(hit.sum()) == 128568
+    # draws: 2 per getRay, then c1, c2 for pixels whose primary ray hit
+    per_pixel = np.where(hit, 4, 2)
+    z = O.xorshf96_draws(int(per_pixel.sum()))
+    first = np.concatenate([[0], np.cumsum(per_pixel)[:-1]])
+    c1 = O.get_rand(z[first[hit] + 2], -1000, 1000)
+    c2 = O.get_rand(z[first[hit] + 3], -1000, 1000)
+    hp = prim[hit]
+    n = hp["normal"]
+    nn = f((f(1.0) / f(512.0)) * f(0.0078125) * f(2.0))
+    noise = np.zeros_like(n)
+    mx = n[:, 0] != 0
+    my = ~mx & (n[:, 1] != 0)
+    mz = ~mx & ~my
+    noise[mx, 1], noise[mx, 2] = c1[mx], c2[mx]
+    noise[my, 0], noise[my, 2] = c1[my], c2[my]
+    noise[mz, 0], noise[mz, 1] = c1[mz], c2[mz]
+    g = O.cast_rays(nodes9, 9, (hp["position"] + n * nn).astype(f), normalize(((n + noise).astype(f) * nn).astype(f)),
+                    coef=0.5, bias=0.0, threads=8)
+    kind, sc = g["hit"] & 0xff, (g["hit"] >> 16) & 0xff
+    assert (int((kind != 0).sum()), int((kind == 2).sum()), int((kind == 1).sum())) == (116671, 77971, 38700)
+    hist = [int(((kind == 2) & (sc == s)).sum()) for s in range(14, 22)]
+    assert hist == [12775, 13589, 14068, 16431, 14450, 3836, 2805, 17]
