@@ -358,9 +358,15 @@ extern "C" int vrc_render_frame(vrc_renderer* r, const vrc_camera* cam, const vr
     if (a.n_items == 0) return VRC_OK;
     HIP_TRY(hipMemsetAsync(a.queue, 0, 4, st));
     uint64_t want = (items + VRC_RENDER_BLOCK - 1) / VRC_RENDER_BLOCK;
-    // k_render_tile needs ~43 KiB LDS per workgroup at depth 9: at most 3 fit a CU
-    const uint32_t bpc = g_tuning.kernel == VRC_KERNEL_TILE ? (g_tuning.blocks_per_cu < 3 ? g_tuning.blocks_per_cu : 3)
-                                                            : g_tuning.blocks_per_cu;
+    // k_render_tile: (depth-1)*2 KiB of stacks + 21 KiB of job pools + 1.5 KiB of tables per workgroup
+    // (38.5 KiB at depth 9): at most 4 fit a CU's 160 KiB; 120 VGPRs allow 4 waves per SIMD as well
+    uint32_t bpc = g_tuning.blocks_per_cu;
+    if (g_tuning.kernel == VRC_KERNEL_TILE) {
+        const uint32_t lds = (s->depth - 1) * 2048u + 4u * 5376u + 1536u;
+        const uint32_t fit = 163840u / lds;
+        if (bpc > fit) bpc = fit;
+        if (bpc > 4u) bpc = 4u;
+    }
     const uint64_t cap = (uint64_t)s->cu_count * bpc;
     const uint32_t grid = (uint32_t)(want < cap ? want : cap);
     HIP_TRY(vrc::launch_render(a, grid, (int)g_tuning.kernel, st));

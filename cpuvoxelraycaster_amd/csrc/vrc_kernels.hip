@@ -472,7 +472,7 @@ k_render(const FrameArgs a)
 namespace {
 constexpr uint32_t TILE_SPP = 4u;                    // samples per pass (pool = 64 * TILE_SPP jobs)
 constexpr uint32_t TILE_POOL = 64u * TILE_SPP;
-constexpr uint32_t TILE_WAVE_LDS = TILE_POOL * 4u * 6u + TILE_POOL;   // px,py,pz,an,li,colors (u32) + meta (u8)
+constexpr uint32_t TILE_WAVE_LDS = TILE_POOL * 4u * 5u + TILE_POOL;   // px,py,pz,an,li (u32) + meta (u8)
 }  // namespace
 
 extern "C" __global__ void __launch_bounds__(VRC_RENDER_BLOCK)
@@ -487,8 +487,10 @@ k_render_tile(const FrameArgs a)
     float* pool_pz = pool_py + TILE_POOL;
     uint32_t* pool_an = reinterpret_cast<uint32_t*>(pool_pz + TILE_POOL);   // albedo | normal mask<<24 | normal signs<<27
     float* pool_li = reinterpret_cast<float*>(pool_an + TILE_POOL);
-    uint32_t* colors = reinterpret_cast<uint32_t*>(pool_li + TILE_POOL);    // final colour of sample si, lane l at [si*64+l]
-    uint8_t* pool_meta = reinterpret_cast<uint8_t*>(colors + TILE_POOL);    // lane | si<<6
+    uint8_t* pool_meta = reinterpret_cast<uint8_t*>(pool_li + TILE_POOL);   // lane | si<<6
+    // A finished job leaves its final colour in its own pool_px slot (the position is dead once the GI
+    // ray has been generated); the owning lane remembers the slot of each of its samples.
+    uint32_t* pool_color = reinterpret_cast<uint32_t*>(pool_px);
     uint8_t* tex = lds_tail + 4u * TILE_WAVE_LDS;
     for (uint32_t i = threadIdx.x; i < 1536u / 4u; i += VRC_RENDER_BLOCK)
         reinterpret_cast<uint32_t*>(tex)[i] = reinterpret_cast<const uint32_t*>(a.tex)[i];
@@ -525,9 +527,16 @@ k_render_tile(const FrameArgs a)
         for (uint32_t s0 = 0u; s0 < spp; s0 += TILE_SPP) {
             const uint32_t ns = min(TILE_SPP, spp - s0);
             uint32_t njobs = 0u;   // wave-uniform
+            uint32_t my_slots = 0u;          // 8 bits per sample of this pass: its job slot in the pool ...
+            uint32_t my_jobs = 0u;           // ... valid where bit si is set
+            uint32_t direct[TILE_SPP];       // colour of samples finished in phase A (no-GI mode / misses)
+#pragma unroll
+            for (uint32_t k = 0; k < TILE_SPP; ++k) direct[k] = 0u;
 
             // ---------------- phase A: primary + shadow, lockstep ----------------
-            for (uint32_t si = 0u; si < ns; ++si) {
+#pragma unroll
+            for (uint32_t si = 0u; si < TILE_SPP; ++si) {
+                if (si >= ns) break;
                 const uint32_t sample = s0 + si;
                 const uint32_t fr = a.p.frame_index + sample;
                 bool hit = false;
@@ -606,12 +615,12 @@ k_render_tile(const FrameArgs a)
                         pool_an[slot] = albedo | (nm << 24) | (sg << 27);
                         pool_li[slot] = light_intensity;
                         pool_meta[slot] = (uint8_t)(lane | (si << 6));
-                    } else {
-                        colors[si * 64u + lane] = 0u;                                // miss -> sf::Color::Black
-                    }
+                        my_slots |= slot << (8u * si);
+                        my_jobs |= 1u << si;
+                    }                                                                // else: miss -> sf::Color::Black
                     njobs += (uint32_t)__popcll(mask);
                 } else {
-                    colors[si * 64u + lane] = hit ? color_mult(albedo, smin(1.0f, smax(0.0f, light_intensity + 0.0f))) : 0u;  // :161-163
+                    direct[si] = hit ? color_mult(albedo, smin(1.0f, smax(0.0f, light_intensity + 0.0f))) : 0u;  // :161-163
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -620,7 +629,7 @@ k_render_tile(const FrameArgs a)
             if (a.p.use_gi && njobs != 0u) {
                 uint32_t next = 0u;            // wave-uniform pool cursor
                 uint32_t stage = ST_NEED_WORK; // ST_GI / ST_GI_SHADOW / ST_NEED_WORK / ST_DONE
-                uint32_t jmeta = 0u, jpix = 0u, jan = 0u, draw = 0u, gi_level = 0u;
+                uint32_t jmeta = 0u, jpix = 0u, jan = 0u, jslot = 0u, draw = 0u, gi_level = 0u;
                 float jlight = 0.0f;
                 float base_px = 0, base_py = 0, base_pz = 0, base_nx = 0, base_ny = 0, base_nz = 0;
                 float pending = 0.0f, dot_gi = 0.0f, dot_gi0 = 0.0f, acc0 = 0.0f, acc1 = 0.0f;
@@ -667,8 +676,7 @@ k_render_tile(const FrameArgs a)
                             float gi;
                             if (gi_level == 0u) gi = smax(0.0f, acc0 / 1.0f);
                             else { acc0 += dot_gi0 * smax(0.0f, acc1 / 1.0f); gi = smax(0.0f, acc0 / 1.0f); }
-                            colors[(jmeta >> 6) * 64u + (jmeta & 63u)] =
-                                color_mult(jan & 0xffffffu, smin(1.0f, smax(0.0f, jlight + gi)));
+                            pool_color[jslot] = color_mult(jan & 0xffffffu, smin(1.0f, smax(0.0f, jlight + gi)));
                             stage = ST_NEED_WORK;
                         }
                     }
@@ -681,6 +689,7 @@ k_render_tile(const FrameArgs a)
                             const uint32_t j = next + rank;
                             if (need) {
                                 if (j < njobs) {
+                                    jslot = j;
                                     jmeta = pool_meta[j];
                                     jan = pool_an[j];
                                     jlight = pool_li[j];
@@ -733,8 +742,10 @@ k_render_tile(const FrameArgs a)
             // ---------------- sink: raycaster.hpp:77-91, samples in order ----------------
             if (valid) {
                 n_pix += ns;
-                for (uint32_t si = 0u; si < ns; ++si) {
-                    const uint32_t c = colors[si * 64u + lane];
+#pragma unroll
+                for (uint32_t si = 0u; si < TILE_SPP; ++si) {
+                    if (si >= ns) break;
+                    const uint32_t c = ((my_jobs >> si) & 1u) ? pool_color[(my_slots >> (8u * si)) & 0xffu] : direct[si];
                     if (a.p.use_samples) { acc_r += c & 0xffu; acc_g += (c >> 8) & 0xffu; acc_b += (c >> 16) & 0xffu; }
                     else {
                         uint32_t old = reinterpret_cast<uint32_t*>(a.image)[pix];
