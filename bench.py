@@ -83,7 +83,8 @@ def main():
     ap.add_argument("--pitch", type=float, default=-0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tuning", default="", help="blocks_per_cu,refill_threshold,chunk")
-    ap.add_argument("--kernel", type=int, default=0, help="frame kernel: 0 tile-phased (default), 1 persistent mixed-stage")
+    ap.add_argument("--kernel", type=int, default=2,
+                    help="frame kernel: 2 stage-synchronous per tile (default), 0 tile-phased with LDS job pool, 1 persistent mixed-stage")
     args = ap.parse_args()
 
     import numpy as np
@@ -264,7 +265,7 @@ def main():
                        "gathered_frame_equals_unsharded": verified},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
-                         "kernel": "k_render_tile" if args.kernel == 0 else "k_render", "kernel_ms": round(kernel_ms, 4), "kernel_ms_max_rank": round(kernel_ms_max, 4),
+                         "kernel": {0: "k_render_tile", 1: "k_render", 2: "k_render_sync"}[args.kernel], "kernel_ms": round(kernel_ms, 4), "kernel_ms_max_rank": round(kernel_ms_max, 4),
                          "algorithmic_bytes_per_launch": int(alg_bytes)},
         }
         if world == 1 and not args.no_cpu_baseline:

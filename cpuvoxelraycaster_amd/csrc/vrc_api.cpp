@@ -39,7 +39,8 @@ struct Tuning {
     uint32_t blocks_per_cu = 4;
     uint32_t refill_threshold = 32;
     uint32_t chunk = 64;
-    uint32_t kernel = VRC_KERNEL_TILE;
+    uint32_t kernel = VRC_KERNEL_SYNC;
+    bool blocks_per_cu_set = false;
 } g_tuning;
 
 }  // namespace
@@ -91,7 +92,7 @@ using vrc::require_device;
 
 extern "C" int vrc_set_kernel(uint32_t kernel)
 {
-    if (kernel > VRC_KERNEL_MIXED) return fail(VRC_ERR_INVALID, "unknown frame kernel %u", kernel);
+    if (kernel > VRC_KERNEL_SYNC) return fail(VRC_ERR_INVALID, "unknown frame kernel %u", kernel);
     g_tuning.kernel = kernel;
     return VRC_OK;
 }
@@ -100,6 +101,7 @@ extern "C" int vrc_set_tuning(uint32_t blocks_per_cu, uint32_t refill_threshold,
 {
     if (blocks_per_cu > 8 || refill_threshold > 64) return fail(VRC_ERR_INVALID, "tuning out of range");
     g_tuning.blocks_per_cu = blocks_per_cu ? blocks_per_cu : 4;
+    g_tuning.blocks_per_cu_set = blocks_per_cu != 0;
     g_tuning.refill_threshold = refill_threshold ? refill_threshold : 32;
     g_tuning.chunk = chunk ? chunk : 64;
     return VRC_OK;
@@ -362,10 +364,16 @@ extern "C" int vrc_render_frame(vrc_renderer* r, const vrc_camera* cam, const vr
     // (38.5 KiB at depth 9): at most 4 fit a CU's 160 KiB; 120 VGPRs allow 4 waves per SIMD as well
     uint32_t bpc = g_tuning.blocks_per_cu;
     if (g_tuning.kernel == VRC_KERNEL_TILE) {
-        const uint32_t lds = (s->depth - 1) * 2048u + 4u * 5376u + 1536u;
+        const uint32_t lds = (s->depth - 1) * 2048u + 4u * vrc::tile_wave_lds_bytes() + 1536u;
         const uint32_t fit = 163840u / lds;
         if (bpc > fit) bpc = fit;
-        if (bpc > 4u) bpc = 4u;
+        if (bpc > vrc::tile_max_blocks_per_cu()) bpc = vrc::tile_max_blocks_per_cu();
+    } else if (g_tuning.kernel == VRC_KERNEL_SYNC) {
+        const uint32_t lds = (s->depth - 1) * 2048u + 1536u;
+        const uint32_t fit = 163840u / lds;
+        bpc = vrc::sync_max_blocks_per_cu();          // its own default: as many as registers allow
+        if (g_tuning.blocks_per_cu_set && g_tuning.blocks_per_cu < bpc) bpc = g_tuning.blocks_per_cu;
+        if (bpc > fit) bpc = fit;
     }
     const uint64_t cap = (uint64_t)s->cu_count * bpc;
     const uint32_t grid = (uint32_t)(want < cap ? want : cap);

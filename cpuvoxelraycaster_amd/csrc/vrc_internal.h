@@ -9,6 +9,7 @@
 #define VRC_RENDER_BLOCK 256
 #define VRC_KERNEL_TILE 0    // k_render_tile: tile-phased (default)
 #define VRC_KERNEL_MIXED 1   // k_render: persistent threads, mixed stages
+#define VRC_KERNEL_SYNC 2    // k_render_sync: stage-synchronous per tile
 
 // opaque handles of include/vrc.h
 struct vrc_scene {
@@ -47,6 +48,9 @@ hipError_t launch_cast_rays(const void* nodes, int depth, uint64_t n, const floa
                             const float* coef, const float* bias, vrc_hit* out, hipStream_t st);
 hipError_t launch_grid_cast(const uint8_t* cells, int X, int Y, int Z, uint64_t n, const float* org, const float* dir,
                             vrc_hit* out, hipStream_t st);
+uint32_t tile_wave_lds_bytes();       // LDS job pool per wave of k_render_tile
+uint32_t tile_max_blocks_per_cu();    // register-limited workgroups per CU of k_render_tile
+uint32_t sync_max_blocks_per_cu();    // ... of k_render_sync
 hipError_t launch_render(const FrameArgs& a, uint32_t grid_blocks, int kernel, hipStream_t st);
 hipError_t launch_resolve(const void* accum, void* image, uint32_t n, hipStream_t st);
 hipError_t launch_fill_u32(void* p, uint32_t value, uint64_t n, hipStream_t st);

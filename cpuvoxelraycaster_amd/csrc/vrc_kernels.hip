@@ -469,13 +469,19 @@ k_render(const FrameArgs a)
 // Per-lane float arithmetic and its order are exactly those of k_render and of
 // the oracle; only the schedule differs.
 
+#ifndef VRC_TILE_SPP
+#define VRC_TILE_SPP 4
+#endif
+#ifndef VRC_TILE_MIN_WAVES
+#define VRC_TILE_MIN_WAVES 4
+#endif
 namespace {
-constexpr uint32_t TILE_SPP = 4u;                    // samples per pass (pool = 64 * TILE_SPP jobs)
+constexpr uint32_t TILE_SPP = VRC_TILE_SPP;          // samples per pass (pool = 64 * TILE_SPP jobs)
 constexpr uint32_t TILE_POOL = 64u * TILE_SPP;
 constexpr uint32_t TILE_WAVE_LDS = TILE_POOL * 4u * 5u + TILE_POOL;   // px,py,pz,an,li (u32) + meta (u8)
 }  // namespace
 
-extern "C" __global__ void __launch_bounds__(VRC_RENDER_BLOCK)
+extern "C" __global__ void __launch_bounds__(VRC_RENDER_BLOCK, VRC_TILE_MIN_WAVES)
 k_render_tile(const FrameArgs a)
 {
     extern __shared__ uint2 lds_dyn[];   // [depth-1][256] stack | 4 x per-wave pool | 1536 B textures
@@ -782,6 +788,215 @@ k_render_tile(const FrameArgs a)
 }
 
 // ---------------------------------------------------------------------------
+// R0 + S1..S4, stage-synchronous per tile ("sync" kernel)
+// ---------------------------------------------------------------------------
+//
+// One wave owns one 8x8 pixel tile at a time; for every sample all 64 lanes run
+// the same stage together: camera ray -> walk -> shade -> shadow ray(s) -> walk ->
+// GI ray -> walk -> GI shadow ray -> walk -> sink.  Lanes whose pixel-sample has
+// ended (miss, GI miss) idle until the tile's stage is over.  Everything lives in
+// registers and the per-wave LDS stack; no job pool, no state machine, so the
+// kernel needs few registers (high occupancy) and every transition (ray
+// generation, the three IEEE divides of ray_setup, finish, shading) runs at full
+// lane utilisation.  Measured against the two schedulers above on C3 it is the
+// fastest: what the refill machinery saves in idle lanes it loses in transition
+// code executed at partial utilisation and in occupancy.
+
+#ifndef VRC_SYNC_MIN_WAVES
+#define VRC_SYNC_MIN_WAVES 5
+#endif
+
+extern "C" __global__ void __launch_bounds__(VRC_RENDER_BLOCK, VRC_SYNC_MIN_WAVES)
+k_render_sync(const FrameArgs a)
+{
+    extern __shared__ uint2 lds_dyn[];   // [depth-1][256] stack | 1536 B textures
+    uint2* stk = lds_dyn + threadIdx.x;
+    uint8_t* tex = reinterpret_cast<uint8_t*>(lds_dyn + (a.depth - 1) * VRC_RENDER_BLOCK);
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t i = threadIdx.x; i < 1536u / 4u; i += VRC_RENDER_BLOCK)
+        reinterpret_cast<uint32_t*>(tex)[i] = reinterpret_cast<const uint32_t*>(a.tex)[i];
+    __syncthreads();
+
+    const uint2* __restrict__ nodes = a.nodes;
+    const int depth = (int)a.depth;
+    const uint32_t W = a.width, H = a.height;
+    const float inv_size = 1.0f / (float)(1u << a.depth);                 // main.cpp:82
+    const float n_normalizer = inv_size * 0.0078125f * 2.0f;              // raycaster.hpp:171-172
+    const float lx = a.p.light_position[0], ly = a.p.light_position[1], lz = a.p.light_position[2];
+    const uint32_t shadow_samples = a.p.shadow_samples ? a.p.shadow_samples : (a.p.use_samples ? 4u : 1u);
+    const uint32_t gi_bounces = a.p.gi_bounces ? a.p.gi_bounces : 1u;
+    const uint32_t spp = a.p.spp ? a.p.spp : 1u;
+    const uint32_t tiles_per_row = (W + 7u) / 8u;
+    const uint32_t n_tiles = a.n_items >> 6;
+    const bool sharded = a.p.row_block && a.p.shard_count > 1u;
+
+    uint32_t n_rays = 0u, n_steps = 0u, n_hits = 0u, n_pix = 0u;
+
+    for (;;) {
+        uint32_t tile = 0u;
+        if (lane == 0u) tile = atomicAdd(a.queue, 1u);
+        tile = __builtin_amdgcn_readfirstlane(tile);
+        if (tile >= n_tiles) break;
+        const uint32_t tx = tile % tiles_per_row, ty = tile / tiles_per_row;
+        const uint32_t px_x = tx * 8u + (lane & 7u);
+        uint32_t px_y = ty * 8u + (lane >> 3);
+        if (sharded) px_y = ((px_y / a.p.row_block) * a.p.shard_count + a.p.shard_index) * a.p.row_block + (px_y % a.p.row_block);
+        const bool valid = px_x < W && px_y < H && pixel_selected(a.p, W, H, px_x, px_y);
+        const uint32_t pix = px_y * W + px_x;
+        uint32_t acc_r = 0u, acc_g = 0u, acc_b = 0u;
+
+        for (uint32_t sample = 0u; sample < spp; ++sample) {
+            const uint32_t fr = a.p.frame_index + sample;
+            uint32_t color = 0u;                                                 // ColorResult: Black
+            if (valid) {
+                // R0: main.cpp:133,145-149; camera_controller.hpp:34-54
+                const float aspect_ratio = (float)W / (float)H;
+                const float lens_x = (float)px_x / (float)H - aspect_ratio * 0.5f;
+                const float lens_y = (float)px_y / (float)H - 0.5f;
+                float sx = lens_x, sy = lens_y, sz = a.cam.fov;
+                normalize3(sx, sy, sz);
+                const float fx = sx * a.cam.focal_length, fy = sy * a.cam.focal_length, fz = sz * a.cam.focal_length;
+                const float r0 = get_rand(counter_rand(a.p.seed, fr, pix, 0u), -0.5f, 0.5f);
+                const float r1 = get_rand(counter_rand(a.p.seed, fr, pix, 1u), -0.5f, 0.5f);
+                const float rvx = a.cam.aperture * r0, rvy = a.cam.aperture * r1, rvz = a.cam.aperture * 0.0f;
+                float vx = fx - rvx, vy = fy - rvy, vz = fz - rvz;
+                normalize3(vx, vy, vz);
+                const float* m = a.cam.rot;
+                float dx = (m[0] * vx + m[1] * vy) + m[2] * vz;
+                float dy = (m[3] * vx + m[4] * vy) + m[5] * vz;
+                float dz = (m[6] * vx + m[7] * vy) + m[8] * vz;
+                const float wx = (m[0] * rvx + m[1] * rvy) + m[2] * rvz;
+                const float wy = (m[3] * rvx + m[4] * rvy) + m[5] * rvz;
+                const float wz = (m[6] * rvx + m[7] * rvy) + m[8] * rvz;
+                float ox = (a.cam.position[0] + wx) * inv_size + 1.0f;
+                float oy = (a.cam.position[1] + wy) * inv_size + 1.0f;
+                float oz = (a.cam.position[2] + wz) * inv_size + 1.0f;
+                Ray r;
+                bool active = ray_setup(r, nodes, ox, oy, oz, dx, dy, dz);
+                while (active) active = ray_step<VRC_RENDER_BLOCK, false>(r, nodes, stk, depth, 0.0f, 0.0f);
+                n_rays += 1u; n_steps += r.complexity;
+                Hit h;
+                ray_finish(r, depth, ox, oy, oz, dx, dy, dz, h);                   // raycaster.hpp:131
+                if (a.prim && sample == 0u) {
+                    uint4* o = reinterpret_cast<uint4*>(a.prim + pix);
+                    o[0] = make_uint4(f2u(h.px), f2u(h.py), f2u(h.pz), f2u(h.nx));
+                    o[1] = make_uint4(f2u(h.ny), f2u(h.nz), f2u(h.u), f2u(h.v));
+                    o[2] = make_uint4(h.hit, h.node, f2u(h.distance), h.complexity);
+                }
+                if (h.hit) {
+                    n_hits += 1u;
+                    // raycaster.hpp:209-240 albedo
+                    const uint8_t* img = (h.ny != 0.0f) ? tex : tex + 768;
+                    const float tu = clampf_(h.u, 0.0f, 1.0f), tv = clampf_(h.v, 0.0f, 1.0f);
+                    uint32_t idx = (uint32_t)(16.0f * tu) + (uint32_t)(16.0f * tv) * 16u;
+                    idx = min(idx, 255u);
+                    const uint32_t albedo = (uint32_t)img[idx * 3] | ((uint32_t)img[idx * 3 + 1] << 8) | ((uint32_t)img[idx * 3 + 2] << 16);
+                    // raycaster.hpp:139,150-158 shadow ray(s): the reference re-casts the identical ray
+                    float light_intensity = 0.0f;
+                    ox = h.px + h.nx * inv_size * 0.001f;
+                    oy = h.py + h.ny * inv_size * 0.001f;
+                    oz = h.pz + h.nz * inv_size * 0.001f;
+                    for (uint32_t i = shadow_samples; i--;) {
+                        dx = lx - ox; dy = ly - oy; dz = lz - oz;
+                        normalize3(dx, dy, dz);
+                        const float lit = smax(0.0f, dot3(dx, dy, dz, h.nx, h.ny, h.nz));       // :156
+                        active = ray_setup(r, nodes, ox, oy, oz, dx, dy, dz);
+                        while (active) active = ray_step<VRC_RENDER_BLOCK, false>(r, nodes, stk, depth, 0.0f, 0.0f);
+                        n_rays += 1u; n_steps += r.complexity;
+                        if (!r.kind) light_intensity = lit;                                  // :155-157
+                    }
+                    // raycaster.hpp:161,169-207 GI (+ the nested second bounce of the extension)
+                    float gi_intensity = 0.0f;
+                    if (a.p.use_gi) {
+                        float base_px = h.px, base_py = h.py, base_pz = h.pz, base_nx = h.nx, base_ny = h.ny, base_nz = h.nz;
+                        float acc[2] = {0.0f, 0.0f}, dgi[2] = {0.0f, 0.0f};
+                        uint32_t draw = 2u, level = 0u;
+                        bool chain = true;
+                        while (chain) {
+                            ox = base_px + base_nx * n_normalizer;                           // :174
+                            oy = base_py + base_ny * n_normalizer;
+                            oz = base_pz + base_nz * n_normalizer;
+                            const float c1 = get_rand(counter_rand(a.p.seed, fr, pix, draw), -1000.0f, 1000.0f);
+                            const float c2 = get_rand(counter_rand(a.p.seed, fr, pix, draw + 1u), -1000.0f, 1000.0f);
+                            draw += 2u;
+                            float qx = 0.0f, qy = 0.0f, qz = 0.0f;
+                            if (base_nx != 0.0f)      { qy = c1; qz = c2; }
+                            else if (base_ny != 0.0f) { qx = c1; qz = c2; }
+                            else if (base_nz != 0.0f) { qx = c1; qy = c2; }
+                            dx = (base_nx + qx) * n_normalizer;                              // :192
+                            dy = (base_ny + qy) * n_normalizer;
+                            dz = (base_nz + qz) * n_normalizer;
+                            normalize3(dx, dy, dz);
+                            const float dot_gi = dot3(dx, dy, dz, base_nx, base_ny, base_nz);   // :193
+                            if (level == 0u) dgi[0] = dot_gi; else dgi[1] = dot_gi;
+                            active = ray_setup(r, nodes, ox, oy, oz, dx, dy, dz);
+                            while (active) active = ray_step<VRC_RENDER_BLOCK>(r, nodes, stk, depth, 0.5f, 0.0f);   // :194
+                            n_rays += 1u; n_steps += r.complexity;
+                            Hit g;
+                            ray_finish(r, depth, ox, oy, oz, dx, dy, dz, g);
+                            chain = false;
+                            if (g.hit) {                                                     // :195-203
+                                ox = g.px + g.nx * n_normalizer;
+                                oy = g.py + g.ny * n_normalizer;
+                                oz = g.pz + g.nz * n_normalizer;
+                                dx = lx - ox; dy = ly - oy; dz = lz - oz;
+                                normalize3(dx, dy, dz);
+                                const float dotl = dot3(g.nx, g.ny, g.nz, dx, dy, dz);         // :200
+                                const float contrib = 1000000.0f * smin(0.5f, smax(0.0f, dotl) * dot_gi);   // :201
+                                active = ray_setup(r, nodes, ox, oy, oz, dx, dy, dz);
+                                while (active) active = ray_step<VRC_RENDER_BLOCK>(r, nodes, stk, depth, 0.5f, 0.0f);   // :198
+                                n_rays += 1u; n_steps += r.complexity;
+                                if (!r.kind) { if (level == 0u) acc[0] += contrib; else acc[1] += contrib; }
+                                if (level + 1u < gi_bounces) {
+                                    base_px = g.px; base_py = g.py; base_pz = g.pz;
+                                    base_nx = g.nx; base_ny = g.ny; base_nz = g.nz;
+                                    level += 1u;
+                                    chain = true;
+                                }
+                            }
+                        }
+                        // :206, innermost level first: gi = max(0, acc0 [+ dot_gi0 * max(0, acc1)])
+                        if (level == 0u) gi_intensity = smax(0.0f, acc[0] / 1.0f);
+                        else { acc[0] += dgi[0] * smax(0.0f, acc[1] / 1.0f); gi_intensity = smax(0.0f, acc[0] / 1.0f); }
+                    }
+                    color = color_mult(albedo, smin(1.0f, smax(0.0f, light_intensity + gi_intensity)));   // :163
+                }
+                // sink: raycaster.hpp:77-91
+                n_pix += 1u;
+                if (a.p.use_samples) { acc_r += color & 0xffu; acc_g += (color >> 8) & 0xffu; acc_b += (color >> 16) & 0xffu; }
+                else {
+                    uint32_t old = reinterpret_cast<uint32_t*>(a.image)[pix];
+                    const uint32_t alpha = old & 0xff000000u;
+                    old = color_mult(old & 0xffffffu, 0.4f);
+                    const uint32_t nw = color_mult(color, 1.0f - 0.4f);
+                    reinterpret_cast<uint32_t*>(a.image)[pix] = color_add_sat(old, nw) | alpha;
+                }
+            }
+        }
+        if (valid && a.p.use_samples) {
+            uint4* ap = reinterpret_cast<uint4*>(a.accum) + pix;                     // raycaster.hpp:87-90
+            uint4 v = *ap;
+            v.x += acc_r; v.y += acc_g; v.z += acc_b; v.w += spp;
+            *ap = v;
+        }
+    }
+
+    uint64_t s_rays = n_rays, s_steps = n_steps, s_hits = n_hits, s_pix = n_pix;
+    for (int off = 32; off > 0; off >>= 1) {
+        s_rays += __shfl_down(s_rays, off);
+        s_steps += __shfl_down(s_steps, off);
+        s_hits += __shfl_down(s_hits, off);
+        s_pix += __shfl_down(s_pix, off);
+    }
+    if (lane == 0u) {
+        atomicAdd(reinterpret_cast<unsigned long long*>(a.stats + 0), (unsigned long long)s_rays);
+        atomicAdd(reinterpret_cast<unsigned long long*>(a.stats + 1), (unsigned long long)s_steps);
+        atomicAdd(reinterpret_cast<unsigned long long*>(a.stats + 2), (unsigned long long)s_hits);
+        atomicAdd(reinterpret_cast<unsigned long long*>(a.stats + 3), (unsigned long long)s_pix);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // S4 sink + plumbing
 // ---------------------------------------------------------------------------
 
@@ -856,14 +1071,21 @@ hipError_t launch_grid_cast(const uint8_t* cells, int X, int Y, int Z, uint64_t 
     return hipGetLastError();
 }
 
+uint32_t tile_wave_lds_bytes() { return TILE_WAVE_LDS; }
+uint32_t tile_max_blocks_per_cu() { return VRC_TILE_MIN_WAVES; }
+uint32_t sync_max_blocks_per_cu() { return VRC_SYNC_MIN_WAVES; }
+
 hipError_t launch_render(const FrameArgs& a, uint32_t grid_blocks, int kernel, hipStream_t st)
 {
     if (kernel == VRC_KERNEL_MIXED) {
         const size_t lds = (size_t)(a.depth - 1) * VRC_RENDER_BLOCK * sizeof(uint2) + 1536;
         hipLaunchKernelGGL(k_render, dim3(grid_blocks), dim3(VRC_RENDER_BLOCK), lds, st, a);
-    } else {
+    } else if (kernel == VRC_KERNEL_TILE) {
         const size_t lds = (size_t)(a.depth - 1) * VRC_RENDER_BLOCK * sizeof(uint2) + 4 * TILE_WAVE_LDS + 1536;
         hipLaunchKernelGGL(k_render_tile, dim3(grid_blocks), dim3(VRC_RENDER_BLOCK), lds, st, a);
+    } else {
+        const size_t lds = (size_t)(a.depth - 1) * VRC_RENDER_BLOCK * sizeof(uint2) + 1536;
+        hipLaunchKernelGGL(k_render_sync, dim3(grid_blocks), dim3(VRC_RENDER_BLOCK), lds, st, a);
     }
     return hipGetLastError();
 }

@@ -220,9 +220,11 @@ void vrc_make_rotation(float angle_x, float angle_y, float rot[9]);
  * chunk: consecutive work items (pixels in 8x8-tile order) a wave reserves per
  * queue atomic (default 64 = one tile: keeps a wave's lanes on one tile). */
 int vrc_set_tuning(uint32_t blocks_per_cu, uint32_t refill_threshold, uint32_t chunk);
-/* Frame kernel: 0 = tile-phased (default: a wave runs an 8x8 tile's primary and
- * shadow rays in lockstep, then its GI rays from an LDS job pool), 1 = persistent
- * threads with mixed stages.  Results are identical; kept for A/B measurement. */
+/* Frame kernel.  2 = stage-synchronous per tile (default, fastest: a wave runs each
+ * stage -- primary, shadow, GI, GI shadow -- of an 8x8 tile's sample together);
+ * 0 = tile-phased with an LDS job pool for the GI rays (ballot + prefix-sum
+ * compaction between bounces); 1 = persistent threads with mixed stages and a
+ * global work queue.  Results are bit-identical; 0 and 1 are kept for A/B. */
 int vrc_set_kernel(uint32_t kernel);
 
 #ifdef __cplusplus

@@ -10,14 +10,14 @@ import oracle_lib as O
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=[0, 1], ids=["tile", "mixed"])
+@pytest.fixture(autouse=True, params=[0, 1, 2], ids=["tile", "mixed", "sync"])
 def frame_kernel(request, built):
     """Every frame test runs on both frame kernels (vrc_set_kernel): 0 = tile-phased
-    (default), 1 = persistent threads with mixed stages."""
+    1 = persistent threads with mixed stages, 2 = stage-synchronous per tile."""
     import cpuvoxelraycaster_amd as vrc
     vrc.capi.check(vrc.capi.load().vrc_set_kernel(request.param))
     yield request.param
-    vrc.capi.check(vrc.capi.load().vrc_set_kernel(0))
+    vrc.capi.check(vrc.capi.load().vrc_set_kernel(2))
 
 
 @pytest.fixture(scope="module")

@@ -18,7 +18,7 @@ def main():
     ap.add_argument("--thr", default="1,8,16,32,48")
     ap.add_argument("--chunk", default="64")
     ap.add_argument("--pitch", type=float, default=-0.5)
-    ap.add_argument("--kernel", default="0", help="frame kernels to sweep: 0 tile-phased, 1 mixed")
+    ap.add_argument("--kernel", default="2", help="frame kernels to sweep: 2 sync, 0 tile-phased, 1 mixed")
     args = ap.parse_args()
     import torch
     import bench
