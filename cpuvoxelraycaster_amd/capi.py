@@ -87,6 +87,7 @@ SYMBOLS = {
     "vrc_make_rotation": (None, [_f32, _f32, _vp]),
     "vrc_set_tuning": (_int, [_u32, _u32, _u32]),
     "vrc_set_kernel": (_int, [_u32]),
+    "vrc_set_sample_chunk": (_int, [_u32]),
 }
 
 _lib = None

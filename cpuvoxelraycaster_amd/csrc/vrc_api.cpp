@@ -41,6 +41,7 @@ struct Tuning {
     uint32_t chunk = 64;
     uint32_t kernel = VRC_KERNEL_SYNC;
     bool blocks_per_cu_set = false;
+    uint32_t sample_chunk = 0;   // 0 = automatic
 } g_tuning;
 
 }  // namespace
@@ -57,7 +58,7 @@ struct vrc_renderer {
     uint32_t width, height;
     void* d_image;  // RGBA8
     void* d_accum;  // 4 x u32 per pixel
-    void* d_stats;  // 4 x u64 + queue head (u32) at byte 32
+    void* d_stats;  // 4 x u64 stats; work-queue heads: 8 x 128-byte lines from byte 128
     vrc_hit* d_prim;
 };
 
@@ -89,6 +90,12 @@ int vrc::require_device(int device, int* cu_count)
 }
 
 using vrc::require_device;
+
+extern "C" int vrc_set_sample_chunk(uint32_t samples_per_unit)
+{
+    g_tuning.sample_chunk = samples_per_unit;
+    return VRC_OK;
+}
 
 extern "C" int vrc_set_kernel(uint32_t kernel)
 {
@@ -283,9 +290,9 @@ extern "C" int vrc_renderer_create(const vrc_scene* s, uint32_t width, uint32_t 
     const uint64_t n = (uint64_t)width * height;
     hipError_t e = hipMalloc(&r->d_image, n * 4);
     if (e == hipSuccess) e = hipMalloc(&r->d_accum, n * 16);
-    if (e == hipSuccess) e = hipMalloc(&r->d_stats, 64);
+    if (e == hipSuccess) e = hipMalloc(&r->d_stats, 2048);
     if (e == hipSuccess) e = hipMemset(r->d_accum, 0, n * 16);
-    if (e == hipSuccess) e = hipMemset(r->d_stats, 0, 64);
+    if (e == hipSuccess) e = hipMemset(r->d_stats, 0, 2048);
     if (e == hipSuccess) e = vrc::launch_fill_u32(r->d_image, 0xff000000u, n, nullptr);  // sf::Image::create: opaque black
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) {
@@ -337,7 +344,7 @@ extern "C" int vrc_render_frame(vrc_renderer* r, const vrc_camera* cam, const vr
     a.accum = (uint32_t*)r->d_accum;
     a.prim = r->d_prim;
     a.stats = (uint64_t*)r->d_stats;
-    a.queue = (uint32_t*)((uint8_t*)r->d_stats + 32);
+    a.queue = (uint32_t*)((uint8_t*)r->d_stats + 128);
     a.depth = s->depth; a.width = r->width; a.height = r->height;
     a.cam = *cam;
     a.p = *p;
@@ -358,7 +365,7 @@ extern "C" int vrc_render_frame(vrc_renderer* r, const vrc_camera* cam, const vr
     a.chunk = g_tuning.chunk;
     a.refill_threshold = g_tuning.refill_threshold;
     if (a.n_items == 0) return VRC_OK;
-    HIP_TRY(hipMemsetAsync(a.queue, 0, 4, st));
+    HIP_TRY(hipMemsetAsync(a.queue, 0, 8 * 128, st));
     uint64_t want = (items + VRC_RENDER_BLOCK - 1) / VRC_RENDER_BLOCK;
     // k_render_tile: (depth-1)*2 KiB of stacks + 21 KiB of job pools + 1.5 KiB of tables per workgroup
     // (38.5 KiB at depth 9): at most 4 fit a CU's 160 KiB; 120 VGPRs allow 4 waves per SIMD as well
@@ -377,6 +384,15 @@ extern "C" int vrc_render_frame(vrc_renderer* r, const vrc_camera* cam, const vr
     }
     const uint64_t cap = (uint64_t)s->cu_count * bpc;
     const uint32_t grid = (uint32_t)(want < cap ? want : cap);
+    a.sample_chunk = 0;
+    if (g_tuning.kernel == VRC_KERNEL_SYNC && a.p.use_samples && a.p.spp > 1) {
+        // keep >= ~4 work units per wave: split a pixel's samples over several units when tiles are few
+        const uint64_t tiles = a.n_items / 64, waves = (uint64_t)grid * (VRC_RENDER_BLOCK / 64);
+        uint32_t c = g_tuning.sample_chunk ? g_tuning.sample_chunk : a.p.spp;
+        if (!g_tuning.sample_chunk)
+            while (c > 1 && tiles * ((a.p.spp + c - 1) / c) < 4 * waves) c = (c + 1) / 2;
+        a.sample_chunk = c < a.p.spp ? c : 0;
+    }
     HIP_TRY(vrc::launch_render(a, grid, (int)g_tuning.kernel, st));
     return VRC_OK;
 }

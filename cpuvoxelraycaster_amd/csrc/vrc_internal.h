@@ -40,6 +40,7 @@ struct FrameArgs {
     uint32_t n_items;         // work items (8x8-tile order over this shard's rows)
     uint32_t chunk;           // items a wave takes from the queue at once
     uint32_t refill_threshold;// leave the traversal loop once this many lanes wait
+    uint32_t sample_chunk;    // k_render_sync: samples per work unit (0 = all spp in one unit)
     vrc_camera cam;
     vrc_frame_params p;
 };

@@ -829,14 +829,33 @@ k_render_sync(const FrameArgs a)
     const uint32_t tiles_per_row = (W + 7u) / 8u;
     const uint32_t n_tiles = a.n_items >> 6;
     const bool sharded = a.p.row_block && a.p.shard_count > 1u;
+    // Work unit = (tile, chunk of `sample_chunk` samples).  With few tiles per GPU (multi-GPU shards)
+    // the host splits a pixel's samples over several units so every wave still gets several units;
+    // the accumulators are then updated with integer atomics (exact, order-independent).
+    const uint32_t chunk = a.sample_chunk ? a.sample_chunk : spp;
+    const uint32_t chunks_per_tile = (spp + chunk - 1u) / chunk;
+    const uint32_t n_units = n_tiles * chunks_per_tile;
 
     uint32_t n_rays = 0u, n_steps = 0u, n_hits = 0u, n_pix = 0u;
 
+    // Work queue with 8 heads (one 128-byte line each): head q hands out units q, q+8, q+16, ...
+    // A wave starts on the head of its workgroup's XCD group (blockIdx % 8: workgroups b and b+8
+    // share an XCD -- a speed hint only) and moves on to the next head when one runs dry, so all
+    // units are handed out whatever the placement.  One head saturates at ~88 dequeues/us, which a
+    // small multi-GPU shard (16 k units in 0.3 ms) would hit.
+    uint32_t head = blockIdx.x & 7u, heads_tried = 0u;
+
     for (;;) {
-        uint32_t tile = 0u;
-        if (lane == 0u) tile = atomicAdd(a.queue, 1u);
-        tile = __builtin_amdgcn_readfirstlane(tile);
-        if (tile >= n_tiles) break;
+        uint32_t unit = 0u;
+        if (lane == 0u) unit = atomicAdd(a.queue + head * 32u, 1u);
+        unit = __builtin_amdgcn_readfirstlane(unit) * 8u + head;
+        if (unit >= n_units) {
+            if (++heads_tried == 8u) break;
+            head = (head + 1u) & 7u;
+            continue;
+        }
+        const uint32_t tile = unit / chunks_per_tile;
+        const uint32_t s_begin = (unit % chunks_per_tile) * chunk, s_end = min(spp, s_begin + chunk);
         const uint32_t tx = tile % tiles_per_row, ty = tile / tiles_per_row;
         const uint32_t px_x = tx * 8u + (lane & 7u);
         uint32_t px_y = ty * 8u + (lane >> 3);
@@ -845,7 +864,7 @@ k_render_sync(const FrameArgs a)
         const uint32_t pix = px_y * W + px_x;
         uint32_t acc_r = 0u, acc_g = 0u, acc_b = 0u;
 
-        for (uint32_t sample = 0u; sample < spp; ++sample) {
+        for (uint32_t sample = s_begin; sample < s_end; ++sample) {
             const uint32_t fr = a.p.frame_index + sample;
             uint32_t color = 0u;                                                 // ColorResult: Black
             if (valid) {
@@ -973,11 +992,16 @@ k_render_sync(const FrameArgs a)
                 }
             }
         }
-        if (valid && a.p.use_samples) {
-            uint4* ap = reinterpret_cast<uint4*>(a.accum) + pix;                     // raycaster.hpp:87-90
-            uint4 v = *ap;
-            v.x += acc_r; v.y += acc_g; v.z += acc_b; v.w += spp;
-            *ap = v;
+        if (valid && a.p.use_samples) {                                              // raycaster.hpp:87-90
+            if (chunks_per_tile == 1u) {
+                uint4* ap = reinterpret_cast<uint4*>(a.accum) + pix;
+                uint4 v = *ap;
+                v.x += acc_r; v.y += acc_g; v.z += acc_b; v.w += spp;
+                *ap = v;
+            } else {
+                uint32_t* ap = a.accum + 4ull * pix;
+                atomicAdd(ap + 0, acc_r); atomicAdd(ap + 1, acc_g); atomicAdd(ap + 2, acc_b); atomicAdd(ap + 3, s_end - s_begin);
+            }
         }
     }
 

@@ -226,6 +226,11 @@ int vrc_set_tuning(uint32_t blocks_per_cu, uint32_t refill_threshold, uint32_t c
  * compaction between bounces); 1 = persistent threads with mixed stages and a
  * global work queue.  Results are bit-identical; 0 and 1 are kept for A/B. */
 int vrc_set_kernel(uint32_t kernel);
+/* Stage-synchronous kernel, sample mode: samples per work unit (tile x sample chunk).  0 =
+ * automatic: all spp in one unit unless the frame (or this GPU's shard) has too few tiles
+ * to give every wave several units; then a pixel's samples are split over units and
+ * accumulated with integer atomics (same sums). */
+int vrc_set_sample_chunk(uint32_t samples_per_unit);
 
 #ifdef __cplusplus
 }

@@ -232,3 +232,17 @@ def test_many_samples_per_call(scene, textures, spp):
 def test_temporal_blend_multiple_samples_per_call(scene, textures):
     """Non-sample mode with spp > 1: the 0.4/0.6 blend is applied once per sample, in order."""
     run_pair(scene, textures, 7, 96, 56, -0.5, spp=3, frames=2, use_gi=1, use_samples=0)
+
+
+@pytest.mark.parametrize("chunk", [1, 2, 3])
+def test_sample_chunked_units(scene, textures, chunk, frame_kernel):
+    """Sync kernel: a pixel's samples split over several work units (multi-GPU small shards),
+    accumulated with integer atomics -- same sums, same counters."""
+    import cpuvoxelraycaster_amd as vrc
+    L = vrc.capi.load()
+    vrc.capi.check(L.vrc_set_sample_chunk(chunk))
+    try:
+        run_pair(scene, textures, 7, 96, 56, -0.5, spp=5, use_gi=1)
+        run_pair(scene, textures, 7, 96, 56, -0.5, spp=2, frames=2, use_gi=1, use_samples=0)   # blend mode ignores it
+    finally:
+        vrc.capi.check(L.vrc_set_sample_chunk(0))
