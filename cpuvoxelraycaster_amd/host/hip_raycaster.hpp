@@ -15,6 +15,8 @@
 #pragma once
 
 #include <cstdint>
+#include <fstream>
+#include <list>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -180,6 +182,34 @@ private:
     uint32_t width_, height_;
     uint32_t frame_index_ = 0;
     Vec3 light_{0, 0, 0};
+};
+
+// Camera-path replay (include/replay.hpp:8-35): whitespace-separated ticks
+// `t x y z view_x view_y`; reading stops at the first malformed tick, a missing
+// file gives an empty list.  The reference has the reader but no caller; here it
+// feeds deterministic multi-frame runs (tools/replay_bench.py speaks the same format).
+struct ReplayElements {
+    float timestamp, x, y, z, view_x, view_y;
+
+    static std::list<ReplayElements> loadFromFile(const std::string& filename)
+    {
+        std::ifstream file(filename);
+        std::list<ReplayElements> result;
+        if (file) {
+            ReplayElements elem;
+            while (file >> elem.timestamp >> elem.x >> elem.y >> elem.z >> elem.view_x >> elem.view_y) result.push_back(elem);
+        }
+        return result;
+    }
+
+    CameraState camera(float aperture = 0.0f, float focal_length = 1.0f, float fov = 1.0f) const
+    {
+        CameraState c;
+        c.position = {x, y, z};
+        c.view_angle = {view_x, view_y};
+        c.aperture = aperture; c.focal_length = focal_length; c.fov = fov;
+        return c;
+    }
 };
 
 }  // namespace vrc_host

@@ -57,3 +57,27 @@ def test_no_gpu_fails_loudly(built):
     nodes = np.zeros(9, vrc.LNODE_DTYPE)
     with pytest.raises(vrc.VrcError):
         vrc.LSVO(nodes, 2)
+
+
+def test_replay_reader_matches_reference_format(built, tmp_path):
+    """include/replay.hpp semantics: whitespace-separated ticks, stop at the first malformed one,
+    missing file -> empty; the C++ host reader and the Python driver agree."""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import replay_bench
+    good = tmp_path / "a.replay"
+    good.write_text("0.0 1 2 3 0.1 -0.2\n0.5 4 5 6\n0.3 0.4\n1.0 7 8 9 x 0\n2.0 1 1 1 1 1\n")
+    hdr = os.path.join(ROOT, "cpuvoxelraycaster_amd", "host", "hip_raycaster.hpp")
+    src = ('#include "%s"\n#include <cstdio>\nint main(int c, char** v){ auto l = vrc_host::ReplayElements::loadFromFile(v[1]);'
+           'std::printf("%%zu", l.size()); for (auto& e : l) std::printf(" %%g %%g %%g %%g %%g %%g", e.timestamp, e.x, e.y, e.z, e.view_x, e.view_y);'
+           'return 0; }\n') % hdr
+    exe = str(tmp_path / "replay_test")
+    subprocess.run(["g++", "-std=c++14", "-x", "c++", "-", "-o", exe, "-L" + os.path.join(ROOT, "cpuvoxelraycaster_amd"),
+                    "-l:libvrc_hip.so", "-Wl,-rpath," + os.path.join(ROOT, "cpuvoxelraycaster_amd")], input=src.encode(), check=True)
+    out = subprocess.run([exe, str(good)], capture_output=True, text=True).stdout.split()
+    ticks = replay_bench.load_replay(str(good))
+    assert int(out[0]) == len(ticks) == 2
+    assert [float(v) for v in out[1:]] == [v for t in ticks for v in t]
+    assert subprocess.run([exe, str(tmp_path / "missing")], capture_output=True, text=True).stdout == "0"
+    assert replay_bench.load_replay(str(tmp_path / "missing")) == []

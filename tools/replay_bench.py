@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Camera-path replay driver: renders the ticks of a replay file in the
+reference's format (include/replay.hpp: `t x y z view_x view_y` per tick, whitespace
+separated) and reports per-frame time.  Without --replay it writes and uses a synthetic
+orbit around the 512^3 terrain."""
+import argparse
+import json
+import math
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def load_replay(path):
+    """Same semantics as ReplayElements::loadFromFile: stop at the first malformed tick."""
+    ticks = []
+    try:
+        tokens = open(path).read().split()
+    except OSError:
+        return ticks
+    for i in range(0, len(tokens) - 5, 6):
+        try:
+            ticks.append(tuple(float(v) for v in tokens[i:i + 6]))
+        except ValueError:
+            break
+    return ticks
+
+
+def synthetic_orbit(path, n=60, size=512.0):
+    with open(path, "w") as f:
+        for i in range(n):
+            a = 2 * math.pi * i / n
+            x, z = size / 2 + 100 * math.cos(a), size / 2 + 100 * math.sin(a)
+            yaw = math.atan2(size / 2 - x, size / 2 - z)   # look at the centre
+            f.write(f"{i / 30:.4f} {x:.3f} {size / 2 - 70:.3f} {z:.3f} {-yaw:.5f} -0.45\n")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--replay", default="")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=4)
+    args = ap.parse_args()
+    import torch
+    import cpuvoxelraycaster_amd as vrc
+    path = args.replay
+    if not path:
+        path = "/tmp/vrc_orbit.replay"
+        synthetic_orbit(path)
+    ticks = load_replay(path)
+    depth = 9
+    svo = vrc.LSVO.fromFastNoiseTerrain(depth, textures=vrc.load_textures())
+    rc = vrc.RayCaster(svo, (args.width, args.height))
+    rc.setLightPosition(vrc.reference_light(depth))
+    rc.use_gi, rc.use_samples, rc.shadow_samples = True, True, 1
+    stream = torch.cuda.current_stream().cuda_stream
+    times = []
+    for (t, x, y, z, vx, vy) in ticks:
+        cam = vrc.make_camera((x, y, z), vrc.make_rotation(vx, vy))
+        rc.resetSamples(stream)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc.renderFrame(cam, spp=args.spp, stream=stream)
+        rc.samples_to_image(stream)
+        e1.record()
+        torch.cuda.synchronize()
+        times.append(e0.elapsed_time(e1))
+    st = rc.stats()
+    times.sort()
+    print(json.dumps({"replay": path, "ticks": len(ticks), "ms_per_frame_median": round(times[len(times) // 2], 3),
+                      "ms_per_frame_max": round(times[-1], 3), "Mrays_per_s": round(st.rays / sum(times) / 1e3, 1),
+                      "rays_per_frame": st.rays // max(1, len(ticks))}))
+
+
+if __name__ == "__main__":
+    main()

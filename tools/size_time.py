@@ -11,7 +11,7 @@ svo = vrc.LSVO.fromFastNoiseTerrain(depth, textures=vrc.load_textures())
 cam = vrc.reference_camera(depth)
 stream = torch.cuda.current_stream().cuda_stream
 print("W     H    spp   ms      ns_per_pixel_sample  rays")
-for (W, H, spp) in [(1920, 1080, 4), (1920, 540, 4), (1920, 270, 4), (1920, 136, 4), (1920, 136, 16), (1920, 136, 64), (960, 136, 4), (1920, 1080, 1)]:
+for (W, H, spp) in [(1920, 8, 4), (1920, 16, 4), (1920, 32, 4), (1920, 64, 4), (1920, 136, 4), (1920, 136, 1), (1920, 272, 1), (1920, 1080, 4)]:
     rc = vrc.RayCaster(svo, (W, H))
     rc.setLightPosition(vrc.reference_light(depth))
     rc.use_gi, rc.use_samples, rc.shadow_samples = True, True, 1
