@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Freeze outputs of the (pinned) oracle as small regression fixtures under tests/golden/:
+
+  rays_d9_4096.npz     4096 mixed rays (tests/raygen.mixed_rays(4096, seed=2024)) on the 512^3 terrain
+                       LSVO with per-ray LOD parameters, and the oracle's 48-byte HitPoint records
+  frame_d9_160x90.npz  accumulators of a 160x90, 3-spp GI frame (pitch -0.5) + ray / iteration counts
+  lsvo_hashes.json     FNV-1a-64 of the LNode arrays for depths 7..10
+
+These are regression vectors (they guard the oracle and the kernels against drift); what ties the
+oracle to the reference is tests/test_oracle_pins.py."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_lib as O
+import raygen
+import cpuvoxelraycaster_amd as vrc
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def fnv1a64(b):
+    h = 1469598103934665603
+    # vectorised in chunks is not possible for FNV; use a C-speed fallback via int.from_bytes per 8 bytes
+    a = np.frombuffer(b, np.uint64)
+    for v in a.tolist():
+        h = ((h ^ v) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def main():
+    heights = vrc.load_terrain_heights()
+    top, side = vrc.load_textures()
+    nodes = O.compile_terrain(9, heights)
+    org, d = raygen.mixed_rays(4096, seed=2024)
+    rng = np.random.default_rng(2024)
+    coef = rng.choice([0.0, 0.0, 0.5, 1.5], size=4096).astype(np.float32)
+    bias = rng.choice([0.0, 0.0, 0.0, 0.004], size=4096).astype(np.float32)
+    hits = O.cast_rays(nodes, 9, org, d, coef=coef, bias=bias)
+    np.savez_compressed(os.path.join(GOLD, "rays_d9_4096.npz"), org=org, dir=d, coef=coef, bias=bias,
+                        hits=np.frombuffer(hits.tobytes(), np.uint8))
+    W, H = 160, 90
+    cam = O.make_camera(vrc.reference_camera_position(9), O.make_rotation(0.0, -0.5))
+    acc = None
+    rays = steps = 0
+    for s in range(3):
+        p = O.make_params(W, H, vrc.reference_light(9), use_gi=1, use_samples=1, shadow_samples=1, frame_index=s)
+        _, acc, _, st = O.render_frame(nodes, 9, top, side, cam, p, accum=acc, threads=8)
+        rays += st.rays
+        steps += st.sum_complexity
+    np.savez_compressed(os.path.join(GOLD, "frame_d9_160x90.npz"), accum=acc, rays=rays, steps=steps)
+    hashes = {}
+    for depth in (7, 8, 9, 10):
+        n = vrc.build_terrain_lsvo(heights, depth) if depth == 10 else O.compile_terrain(depth, heights)
+        hashes[str(depth)] = {"nodes": int(len(n)), "fnv1a64_of_u64_words": f"{fnv1a64(n.tobytes()):016x}"}
+        print(depth, hashes[str(depth)])
+    json.dump(hashes, open(os.path.join(GOLD, "lsvo_hashes.json"), "w"), indent=2)
+
+
+if __name__ == "__main__":
+    main()
