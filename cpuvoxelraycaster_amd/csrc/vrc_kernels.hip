@@ -24,11 +24,13 @@ using namespace vrc;
 // T1: batch per-ray operator
 // ---------------------------------------------------------------------------
 
-extern "C" __global__ void __launch_bounds__(256)
-k_cast_rays(const uint2* __restrict__ nodes, int depth, uint64_t n,
-            const float* __restrict__ org, const float* __restrict__ dir,
-            const float* __restrict__ coef_a, const float* __restrict__ bias_a,
-            vrc_hit* __restrict__ out)
+// LOD = false when the caller passes neither ray_size_coef nor ray_size_bias (both 0): the LOD test
+// of lsvo.hpp:82 cannot fire then and is compiled out (see ray_step).
+template <bool LOD>
+__device__ __forceinline__ void cast_rays_body(const uint2* __restrict__ nodes, int depth, uint64_t n,
+                                               const float* __restrict__ org, const float* __restrict__ dir,
+                                               const float* __restrict__ coef_a, const float* __restrict__ bias_a,
+                                               vrc_hit* __restrict__ out)
 {
     extern __shared__ uint2 lds_stack[];  // [depth-1][blockDim.x]
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -40,7 +42,7 @@ k_cast_rays(const uint2* __restrict__ nodes, int depth, uint64_t n,
     Ray r;
     bool active = ray_setup(r, nodes, ox, oy, oz, dx, dy, dz);
     uint2* stk = lds_stack + threadIdx.x;
-    while (active) active = ray_step<256>(r, nodes, stk, depth, coef, bias);
+    while (active) active = ray_step<256, LOD>(r, nodes, stk, depth, coef, bias);
     Hit h;
     ray_finish(r, depth, ox, oy, oz, dx, dy, dz, h);
     // 48-byte record as three 16-byte stores
@@ -48,6 +50,20 @@ k_cast_rays(const uint2* __restrict__ nodes, int depth, uint64_t n,
     o[0] = make_uint4(f2u(h.px), f2u(h.py), f2u(h.pz), f2u(h.nx));
     o[1] = make_uint4(f2u(h.ny), f2u(h.nz), f2u(h.u), f2u(h.v));
     o[2] = make_uint4(h.hit, h.node, f2u(h.distance), h.complexity);
+}
+
+extern "C" __global__ void __launch_bounds__(256)
+k_cast_rays(const uint2* __restrict__ nodes, int depth, uint64_t n, const float* __restrict__ org, const float* __restrict__ dir,
+            const float* __restrict__ coef_a, const float* __restrict__ bias_a, vrc_hit* __restrict__ out)
+{
+    cast_rays_body<true>(nodes, depth, n, org, dir, coef_a, bias_a, out);
+}
+
+extern "C" __global__ void __launch_bounds__(256)
+k_cast_rays_nolod(const uint2* __restrict__ nodes, int depth, uint64_t n, const float* __restrict__ org,
+                  const float* __restrict__ dir, vrc_hit* __restrict__ out)
+{
+    cast_rays_body<false>(nodes, depth, n, org, dir, nullptr, nullptr, out);
 }
 
 // ---------------------------------------------------------------------------
@@ -1080,8 +1096,11 @@ hipError_t launch_cast_rays(const void* nodes, int depth, uint64_t n, const floa
     const int block = 256;
     const uint64_t grid = (n + block - 1) / block;
     const size_t lds = (size_t)(depth - 1) * block * sizeof(uint2);
-    hipLaunchKernelGGL(k_cast_rays, dim3((uint32_t)grid), dim3(block), lds, st,
-                       (const uint2*)nodes, depth, n, org, dir, coef, bias, out);
+    if (!coef && !bias)
+        hipLaunchKernelGGL(k_cast_rays_nolod, dim3((uint32_t)grid), dim3(block), lds, st, (const uint2*)nodes, depth, n, org, dir, out);
+    else
+        hipLaunchKernelGGL(k_cast_rays, dim3((uint32_t)grid), dim3(block), lds, st,
+                           (const uint2*)nodes, depth, n, org, dir, coef, bias, out);
     return hipGetLastError();
 }
 
