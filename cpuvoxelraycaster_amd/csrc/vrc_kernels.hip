@@ -1,14 +1,18 @@
 // vrc_kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4, wave64) for the
 // voxel ray-traversal hot path, plus their launchers.
 //
-//   k_cast_rays   T1   batch LSVO<N>::castRay (lsvo.hpp:33-172), one lane per ray
-//   k_render      R0 + S1..S4  persistent-threads frame kernel: every lane runs a
-//                 small state machine primary -> shadow -> GI -> GI-shadow over ONE
-//                 shared traversal loop, lanes that run out of rays are refilled
-//                 from a work queue by wave ballot / prefix-sum (mbcnt)
-//   k_grid_cast   G1   Grid3D::castRay (grid_3d.hpp:36-132)
-//   k_resolve / k_fill / k_pack / k_unpack   S4 sink + multi-GPU shard plumbing
+//   k_cast_rays(_nolod)  T1   batch LSVO<N>::castRay (lsvo.hpp:33-172), one lane per ray
+//   k_render_sync   R0 + S1..S4  frame kernel (default): a wave owns an 8x8 pixel tile and runs each
+//                   stage of a sample -- primary, shadow, GI, GI shadow -- for all 64 lanes together
+//   k_render_tile   same frame, scheduler 0: lockstep primary/shadow, then the GI rays from a per-wave
+//                   LDS job pool filled by wave ballot / prefix-sum (mbcnt) compaction
+//   k_render        same frame, scheduler 1: persistent threads, every lane runs the whole
+//                   primary -> shadow -> GI -> GI-shadow state machine over ONE shared traversal loop
+//                   and is refilled from a global work queue
+//   k_grid_cast     G1   Grid3D::castRay (grid_3d.hpp:36-132)
+//   k_resolve / k_fill_u32 / k_pack_shard / k_unpack_shards   S4 sink + multi-GPU shard plumbing
 //
+// The three frame kernels produce bit-identical results (DESIGN.md section 4 has the measurements).
 // No MFMA anywhere: this is dependent 8-byte gathers, not a contraction.
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see build.py).
 #include <hip/hip_runtime.h>
@@ -200,7 +204,6 @@ k_render(const FrameArgs a)
     uint32_t stage = ST_NEED_WORK;
     uint32_t pix = 0u, px_x = 0u, px_y = 0u, sample = 0u;
     uint32_t acc_r = 0u, acc_g = 0u, acc_b = 0u;   // this pixel's colour summed over the samples of this call
-    uint32_t last_color = 0u;
     uint32_t albedo = 0u;
     float base_px = 0, base_py = 0, base_pz = 0;   // point the next GI ray starts from
     float base_nx = 0, base_ny = 0, base_nz = 0;
@@ -457,7 +460,6 @@ k_render(const FrameArgs a)
         atomicAdd(reinterpret_cast<unsigned long long*>(a.stats + 2), (unsigned long long)s_hits);
         atomicAdd(reinterpret_cast<unsigned long long*>(a.stats + 3), (unsigned long long)s_pix);
     }
-    (void)last_color;
 }
 
 // ---------------------------------------------------------------------------
