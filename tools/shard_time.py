@@ -22,7 +22,7 @@ L = vrc.capi.load()
 print("N  bpc  median_ms   (ideal = t(N=1)/N)")
 base = None
 for N in (1, 2, 4, 8):
-    for bpc in (2, 3, 5):
+    for bpc in [int(v) for v in os.environ.get('BPCS', '3,5').split(',')]:
         vrc.capi.check(L.vrc_set_tuning(bpc, 24, 64))
         ts = []
         for it in range(8):
@@ -37,6 +37,6 @@ for N in (1, 2, 4, 8):
                 ts.append(e0.elapsed_time(e1))
         ts.sort()
         t = ts[len(ts) // 2]
-        if N == 1 and bpc == 5:
+        if N == 1 and base is None:
             base = t
         print(f"{N}  {bpc}   {t:8.3f}" + (f"   ideal {base / N:6.3f}  eff {base / N / t:5.2f}" if base else ""))
