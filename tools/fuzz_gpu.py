@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Long differential fuzz on the GPU box: random scenes / rays / frame configurations, HIP path
+vs the oracle, for a given number of seconds.  Any mismatch is printed and makes the exit code 1."""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=300)
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+    import cpuvoxelraycaster_amd as vrc
+    import oracle_lib as O
+    import raygen
+    L = vrc.capi.load()
+    top, side = vrc.load_textures()
+    heights = vrc.load_terrain_heights()
+    t0 = time.time()
+    it = bad = rays_total = frames = 0
+    while time.time() - t0 < args.seconds:
+        rng = np.random.default_rng(args.seed * 100003 + it)
+        it += 1
+        if it % 3:
+            # random volume, random rays with LOD parameters
+            depth = int(rng.integers(2, 8))
+            S = 1 << depth
+            vol = (rng.random((S, S, S)) < float(rng.choice([0.001, 0.01, 0.05, 0.2, 0.6, 1.0]))).astype(np.uint8)
+            svo = vrc.LSVO.fromVolume(vol, depth)
+            nodes = svo.downloadNodes()
+            ref_nodes = O.compile_voxels(depth, np.argwhere(vol)) if depth <= 5 else nodes
+            if not np.array_equal(nodes.view(np.uint64), ref_nodes.view(np.uint64)):
+                print("BUILDER MISMATCH", it, depth); bad += 1
+            n = int(rng.integers(1, 60000))
+            org, d = raygen.mixed_rays(max(n, 16), seed=int(rng.integers(1 << 30)))
+            coef = rng.choice([0.0, 0.0, 0.3, 0.5, 2.0], size=len(org)).astype(np.float32)
+            bias = rng.choice([0.0, 0.0, 0.0, 0.01], size=len(org)).astype(np.float32)
+            got = svo.castRays(org, d, coef=coef, bias=bias)
+            ref = O.cast_rays(nodes, depth, org, d, coef=coef, bias=bias, threads=16)
+            rays_total += len(org)
+            if got.tobytes() != ref.tobytes():
+                print("RAY MISMATCH", it, depth, len(org)); bad += 1
+        else:
+            # random frame configuration on the terrain, random kernel
+            depth = int(rng.choice([7, 8, 9]))
+            svo = vrc.LSVO.fromFastNoiseTerrain(depth, textures=(top, side))
+            nodes = svo.downloadNodes()
+            W, H = int(rng.integers(1, 200)), int(rng.integers(1, 120))
+            kernel = int(rng.integers(0, 3))
+            vrc.capi.check(L.vrc_set_kernel(kernel))
+            vrc.capi.check(L.vrc_set_sample_chunk(int(rng.integers(0, 4))))
+            rc = vrc.RayCaster(svo, (W, H))
+            S = float(1 << depth)
+            light = vrc.reference_light(depth)
+            rc.setLightPosition(light)
+            use_samples = int(rng.integers(0, 2))
+            rc.use_gi, rc.use_samples = bool(rng.integers(0, 2)), bool(use_samples)
+            rc.shadow_samples = int(rng.choice([0, 1, 2]))
+            rc.gi_bounces = int(rng.choice([1, 1, 2]))
+            rc.seed = int(rng.integers(1 << 31))
+            pos = (S / 2 + rng.uniform(-S / 8, S / 8), S / 2 - rng.uniform(56, 56 + S / 8), S / 2 + rng.uniform(-S / 8, S / 8))
+            cam = vrc.make_camera(pos, vrc.make_rotation(float(rng.uniform(-3, 3)), float(rng.uniform(-1.3, 0.3))),
+                                  fov=float(rng.uniform(0.5, 1.5)), aperture=float(rng.choice([0.0, 0.3, 2.0])),
+                                  focal_length=float(rng.uniform(1, 120)))
+            spp = int(rng.integers(1, 7))
+            nfr = int(rng.integers(1, 3))
+            checker = bool(rng.integers(0, 2)) and not use_samples
+            ocam = O.make_camera(tuple(cam.position), tuple(cam.rot), cam.fov, cam.aperture, cam.focal_length)
+            oimg = oacc = None
+            rr = ss = 0
+            fi = 0
+            for f in range(nfr):
+                par = (f % 2) if checker else -1
+                rc.renderFrame(cam, spp=spp, checker_parity=par)
+                for s in range(spp):
+                    p = O.make_params(W, H, light, use_gi=int(rc.use_gi), use_samples=use_samples, shadow_samples=rc.shadow_samples,
+                                      gi_bounces=rc.gi_bounces, checker_parity=par, seed=rc.seed, frame_index=fi)
+                    oimg, oacc, _, st = O.render_frame(nodes, depth, top, side, ocam, p, image=oimg, accum=oacc, threads=16)
+                    rr += st.rays; ss += st.sum_complexity; fi += 1
+            st = rc.stats()
+            ok = (st.rays, st.sum_complexity) == (rr, ss)
+            ok = ok and (np.array_equal(rc.readAccum(), oacc) if use_samples else np.array_equal(rc.readImage(), oimg))
+            frames += 1
+            rays_total += rr
+            if not ok:
+                print("FRAME MISMATCH", it, dict(depth=depth, W=W, H=H, kernel=kernel, spp=spp, gi=rc.use_gi, samples=use_samples)); bad += 1
+            vrc.capi.check(L.vrc_set_kernel(2)); vrc.capi.check(L.vrc_set_sample_chunk(0))
+    print(f"fuzz: {it} cases ({frames} frames), {rays_total} rays compared, {bad} mismatches, {time.time() - t0:.0f} s")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
