@@ -77,8 +77,8 @@ def cpu_baseline(cfg, nodes, textures, cam, light, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--pitch", type=float, default=-0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
