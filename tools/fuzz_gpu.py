@@ -49,8 +49,23 @@ def main():
                 print("RAY MISMATCH", it, depth, len(org)); bad += 1
         else:
             # random frame configuration on the terrain, random kernel
-            depth = int(rng.choice([7, 8, 9]))
-            svo = vrc.LSVO.fromFastNoiseTerrain(depth, textures=(top, side))
+            if rng.integers(0, 2):
+                depth = int(rng.choice([7, 8, 9]))
+                svo = vrc.LSVO.fromFastNoiseTerrain(depth, textures=(top, side))
+            else:
+                # random blobs / slabs / noise volume: frames through arbitrary geometry, camera anywhere
+                depth = int(rng.integers(4, 8))
+                S0 = 1 << depth
+                g = np.indices((S0, S0, S0)).astype(np.float32)
+                vol = np.zeros((S0, S0, S0), np.uint8)
+                for _ in range(int(rng.integers(1, 6))):
+                    c = rng.uniform(0, S0, 3)
+                    r = rng.uniform(1, S0 / 3)
+                    vol |= (((g[0] - c[0]) ** 2 + (g[1] - c[1]) ** 2 + (g[2] - c[2]) ** 2) < r * r).astype(np.uint8)
+                vol |= (rng.random((S0, S0, S0)) < 0.01).astype(np.uint8)
+                if rng.integers(0, 2):
+                    vol[:, int(rng.integers(0, S0)), :] = 1
+                svo = vrc.LSVO.fromVolume(vol, depth, textures=(top, side))
             nodes = svo.downloadNodes()
             W, H = int(rng.integers(1, 200)), int(rng.integers(1, 120))
             kernel = int(rng.integers(0, 3))
