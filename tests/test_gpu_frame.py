@@ -246,3 +246,34 @@ def test_sample_chunked_units(scene, textures, chunk, frame_kernel):
         run_pair(scene, textures, 7, 96, 56, -0.5, spp=2, frames=2, use_gi=1, use_samples=0)   # blend mode ignores it
     finally:
         vrc.capi.check(L.vrc_set_sample_chunk(0))
+
+
+def test_gpu_pack_unpack_match_documented_layout(scene, textures):
+    """k_pack_shard / k_unpack_shards against the numpy restatement of the shard layout in
+    cpuvoxelraycaster_amd/dist.py (the one the world-size-2 gloo test exercises)."""
+    import torch
+    import cpuvoxelraycaster_amd as vrc
+    import cpuvoxelraycaster_amd.dist as vd
+    nodes, svo = scene[7]
+    W, H, N = 203, 101, 3
+    rc = vrc.RayCaster(svo, (W, H))
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (H, W, 4), dtype=np.uint8)
+    rc.writeImage(img)
+    L = vrc.capi.load()
+    nbytes = L.vrc_shard_bytes(W, H, vd.ROW_BLOCK, N)
+    assert nbytes == vd.shard_bytes(W, H, vd.ROW_BLOCK, N)
+    parts = []
+    for k in range(N):
+        buf = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+        rc.packShard(vd.ROW_BLOCK, k, N, buf.data_ptr())
+        torch.cuda.synchronize()
+        got = buf.cpu().numpy()
+        assert np.array_equal(got, vd.pack_shard_np(img, vd.ROW_BLOCK, k, N))
+        parts.append(got)
+    gathered = torch.from_numpy(np.concatenate(parts)).cuda()
+    out = torch.zeros(H * W * 4, dtype=torch.uint8, device="cuda")
+    vrc.capi.check(L.vrc_unpack_shards(vrc.capi.ptr(gathered.data_ptr()), W, H, vd.ROW_BLOCK, N, vrc.capi.ptr(out.data_ptr()), None))
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy().reshape(H, W, 4), img)
+    assert np.array_equal(vd.unpack_shards_np(np.concatenate(parts), W, H, vd.ROW_BLOCK, N), img)
