@@ -167,10 +167,13 @@ __device__ __forceinline__ bool ray_step(Ray& r, const uint2* __restrict__ nodes
     const uint32_t masks = nd.x >> child_shift;                         // bit 8: child, bit 16: leaf
     // The nested tests of :81-95 as flat predicates (same comparisons, same order of
     // evaluation where it matters: every operand is a plain value, no side effects).
-    const bool exists = (masks & 0x100u) && r.t_min <= r.t_max;        // :81
-    const bool lod = LOD && exists && (tc_max * coef + bias >= r.scale_f);   // :82
+    // :81 `child exists && t_min <= t_max` guards both the LOD test (:82) and the span test (:89).  The
+    // span test alone implies it: tv_max = min(t_max, tc_max) <= t_max (no NaN in the walk), so the
+    // separate comparison is only evaluated where the LOD test needs it.
+    const bool child = (masks & 0x100u) != 0u;
+    const bool lod = LOD && child && r.t_min <= r.t_max && (tc_max * coef + bias >= r.scale_f);   // :81-82
     const float tv_max = tmin(r.t_max, tc_max);                         // :86
-    const bool inside = exists && !lod && r.t_min <= tv_max;            // :89
+    const bool inside = child && !lod && r.t_min <= tv_max;             // :81,:89
     const bool leaf = inside && (masks & 0x10000u);                     // :90-92
     if (lod || leaf) {                                                  // :83-84 / :93-94
         r.kind = lod ? 2u : 1u; r.shift = child_shift;
@@ -193,7 +196,9 @@ __device__ __forceinline__ bool ray_step(Ray& r, const uint2* __restrict__ nodes
         if (thy > r.t_min) { r.child_offset ^= 2u; r.py += r.scale_f; }
         if (thz > r.t_min) { r.child_offset ^= 4u; r.pz += r.scale_f; }
         r.t_max = tv_max;                                               // :110
-        return r.scale > depth;                                         // :72 (scale < 23 holds)
+        // :72 `scale < 23 && scale > N` holds after every descend for N <= VRC_MAX_DEPTH = 11: leaf
+        // level children sit at scale 23 - N, so a descend ends at scale >= 24 - N >= 13 > N.
+        return true;
     }
     const uint32_t opx = f2u(r.px), opy = f2u(r.py), opz = f2u(r.pz);   // pos before the step
     uint32_t step_mask = 0u;                                            // :115-118
@@ -215,9 +220,10 @@ __device__ __forceinline__ bool ray_step(Ray& r, const uint2* __restrict__ nodes
         // of the highest set bit.  differing_bits == 0 (unreachable, UB in the
         // reference) yields scale = -1 and ends the walk as a miss.
         r.scale = 31 - __clz((int)differing_bits);
-        if (r.scale >= SVO_MAX || r.scale <= depth) {
-            // ray left the root (scale == 23): the reference reads the never
-            // written stack[N] here and then leaves the loop (App. A.9).
+        if ((uint32_t)r.scale >= (uint32_t)SVO_MAX) {
+            // ray left the root (scale == 23; or the unreachable -1): the reference reads the never
+            // written stack[N] here and then leaves the loop (App. A.9).  A pop never lands at
+            // scale <= N for N <= 11 (see the descend comment), so :72's lower bound is not tested.
             return false;
         }
         r.scale_f = u2f((uint32_t)(r.scale - SVO_MAX + 127) << SVO_MAX);  // :133
