@@ -110,7 +110,7 @@ __device__ __forceinline__ bool finite3(float x, float y, float z)
 // whether the walk may start: false for non-finite input, for which the
 // reference's loop never terminates (no comparison at :116-118 holds) -- defined
 // as an immediate miss with complexity 0, in the oracle too.
-__device__ __forceinline__ bool ray_setup(Ray& r, const uint2* __restrict__ nodes,
+__device__ __forceinline__ bool ray_setup(Ray& r, const uint2 root,
                                           float ox, float oy, float oz, float& dx, float& dy, float& dz)
 {
     const float EPS = 1.0f / (float)(1 << SVO_MAX);
@@ -140,7 +140,7 @@ __device__ __forceinline__ bool ray_setup(Ray& r, const uint2* __restrict__ node
     r.complexity = 0u;
     r.kind = 0u;
     r.shift = 0u;
-    r.nd = nodes[0];
+    r.nd = root;       // raw_data[0], loaded once per kernel by the caller
     return finite3(ox, oy, oz) && finite3(dx, dy, dz);
 }
 

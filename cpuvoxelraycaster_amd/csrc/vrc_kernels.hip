@@ -43,8 +43,9 @@ __device__ __forceinline__ void cast_rays_body(const uint2* __restrict__ nodes, 
     float dx = dir[3 * i + 0], dy = dir[3 * i + 1], dz = dir[3 * i + 2];
     const float coef = coef_a ? coef_a[i] : 0.0f;
     const float bias = bias_a ? bias_a[i] : 0.0f;
+    const uint2 root = nodes[0];
     Ray r;
-    bool active = ray_setup(r, nodes, ox, oy, oz, dx, dy, dz);
+    bool active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
     uint2* stk = lds_stack + threadIdx.x;
     while (active) active = ray_step<256, LOD>(r, nodes, stk, depth, coef, bias);
     Hit h;
@@ -186,6 +187,7 @@ k_render(const FrameArgs a)
     __syncthreads();
 
     const uint2* __restrict__ nodes = a.nodes;
+    const uint2 root = nodes[0];
     const int depth = (int)a.depth;
     const uint32_t W = a.width, H = a.height;
     const float inv_size = 1.0f / (float)(1u << a.depth);                 // main.cpp:82
@@ -442,7 +444,7 @@ k_render(const FrameArgs a)
             stage = ST_PRIMARY;
             launch = true;
         }
-        if (launch) active = ray_setup(r, nodes, ox, oy, oz, dx, dy, dz);
+        if (launch) active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
         if (__ballot(stage != ST_DONE) == 0ull) break;
     }
 
@@ -521,6 +523,7 @@ k_render_tile(const FrameArgs a)
     __syncthreads();
 
     const uint2* __restrict__ nodes = a.nodes;
+    const uint2 root = nodes[0];
     const int depth = (int)a.depth;
     const uint32_t W = a.width, H = a.height;
     const float inv_size = 1.0f / (float)(1u << a.depth);                 // main.cpp:82
@@ -592,7 +595,7 @@ k_render_tile(const FrameArgs a)
                     float oy = (a.cam.position[1] + wy) * inv_size + 1.0f;
                     float oz = (a.cam.position[2] + wz) * inv_size + 1.0f;
                     Ray r;
-                    bool active = ray_setup(r, nodes, ox, oy, oz, dx, dy, dz);
+                    bool active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
                     while (active) active = ray_step<VRC_RENDER_BLOCK, false>(r, nodes, stk, depth, 0.0f, 0.0f);
                     n_rays += 1u; n_steps += r.complexity;
                     ray_finish(r, depth, ox, oy, oz, dx, dy, dz, h);               // raycaster.hpp:131
@@ -619,7 +622,7 @@ k_render_tile(const FrameArgs a)
                             dx = lx - ox; dy = ly - oy; dz = lz - oz;
                             normalize3(dx, dy, dz);
                             const float lit = smax(0.0f, dot3(dx, dy, dz, h.nx, h.ny, h.nz));   // :156
-                            active = ray_setup(r, nodes, ox, oy, oz, dx, dy, dz);
+                            active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
                             while (active) active = ray_step<VRC_RENDER_BLOCK, false>(r, nodes, stk, depth, 0.0f, 0.0f);
                             n_rays += 1u; n_steps += r.complexity;
                             if (!r.kind) light_intensity = lit;                              // :155-157
@@ -757,7 +760,7 @@ k_render_tile(const FrameArgs a)
                         stage = ST_GI;
                         launch = true;
                     }
-                    if (launch) active = ray_setup(r, nodes, ox, oy, oz, dx, dy, dz);
+                    if (launch) active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
                     if (__ballot(stage != ST_DONE) == 0ull) break;
                 }
             }
@@ -836,6 +839,7 @@ k_render_sync(const FrameArgs a)
     __syncthreads();
 
     const uint2* __restrict__ nodes = a.nodes;
+    const uint2 root = nodes[0];
     const int depth = (int)a.depth;
     const uint32_t W = a.width, H = a.height;
     const float inv_size = 1.0f / (float)(1u << a.depth);                 // main.cpp:82
@@ -909,7 +913,7 @@ k_render_sync(const FrameArgs a)
                 float oy = (a.cam.position[1] + wy) * inv_size + 1.0f;
                 float oz = (a.cam.position[2] + wz) * inv_size + 1.0f;
                 Ray r;
-                bool active = ray_setup(r, nodes, ox, oy, oz, dx, dy, dz);
+                bool active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
                 while (active) active = ray_step<VRC_RENDER_BLOCK, false>(r, nodes, stk, depth, 0.0f, 0.0f);
                 n_rays += 1u; n_steps += r.complexity;
                 Hit h;
@@ -937,7 +941,7 @@ k_render_sync(const FrameArgs a)
                         dx = lx - ox; dy = ly - oy; dz = lz - oz;
                         normalize3(dx, dy, dz);
                         const float lit = smax(0.0f, dot3(dx, dy, dz, h.nx, h.ny, h.nz));       // :156
-                        active = ray_setup(r, nodes, ox, oy, oz, dx, dy, dz);
+                        active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
                         while (active) active = ray_step<VRC_RENDER_BLOCK, false>(r, nodes, stk, depth, 0.0f, 0.0f);
                         n_rays += 1u; n_steps += r.complexity;
                         if (!r.kind) light_intensity = lit;                                  // :155-157
@@ -966,7 +970,7 @@ k_render_sync(const FrameArgs a)
                             normalize3(dx, dy, dz);
                             const float dot_gi = dot3(dx, dy, dz, base_nx, base_ny, base_nz);   // :193
                             if (level == 0u) dgi[0] = dot_gi; else dgi[1] = dot_gi;
-                            active = ray_setup(r, nodes, ox, oy, oz, dx, dy, dz);
+                            active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
                             while (active) active = ray_step<VRC_RENDER_BLOCK>(r, nodes, stk, depth, 0.5f, 0.0f);   // :194
                             n_rays += 1u; n_steps += r.complexity;
                             Hit g;
@@ -980,7 +984,7 @@ k_render_sync(const FrameArgs a)
                                 normalize3(dx, dy, dz);
                                 const float dotl = dot3(g.nx, g.ny, g.nz, dx, dy, dz);         // :200
                                 const float contrib = 1000000.0f * smin(0.5f, smax(0.0f, dotl) * dot_gi);   // :201
-                                active = ray_setup(r, nodes, ox, oy, oz, dx, dy, dz);
+                                active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
                                 while (active) active = ray_step<VRC_RENDER_BLOCK>(r, nodes, stk, depth, 0.5f, 0.0f);   // :198
                                 n_rays += 1u; n_steps += r.complexity;
                                 if (!r.kind) { if (level == 0u) acc[0] += contrib; else acc[1] += contrib; }
