@@ -189,22 +189,24 @@ __device__ __forceinline__ bool ray_step(Ray& r, const uint2* __restrict__ nodes
         r.h = tc_max;                                                   // :101
         r.parent_id += nd.y + child_shift;                              // :103
         r.nd = nodes[r.parent_id];
-        r.child_offset = 0u;
         --r.scale;
         r.scale_f = half;
-        if (thx > r.t_min) { r.child_offset ^= 1u; r.px += r.scale_f; }   // :107-109
-        if (thy > r.t_min) { r.child_offset ^= 2u; r.py += r.scale_f; }
-        if (thz > r.t_min) { r.child_offset ^= 4u; r.pz += r.scale_f; }
+        const bool bx = thx > r.t_min, by = thy > r.t_min, bz = thz > r.t_min;   // :107-109
+        r.child_offset = (bx ? 1u : 0u) | (by ? 2u : 0u) | (bz ? 4u : 0u);
+        r.px += bx ? half : 0.0f;      // x + 0 == x bit for bit (x is never -0 here)
+        r.py += by ? half : 0.0f;
+        r.pz += bz ? half : 0.0f;
         r.t_max = tv_max;                                               // :110
         // :72 `scale < 23 && scale > N` holds after every descend for N <= VRC_MAX_DEPTH = 11: leaf
         // level children sit at scale 23 - N, so a descend ends at scale >= 24 - N >= 13 > N.
         return true;
     }
     const uint32_t opx = f2u(r.px), opy = f2u(r.py), opz = f2u(r.pz);   // pos before the step
-    uint32_t step_mask = 0u;                                            // :115-118
-    if (cx <= tc_max) { step_mask ^= 1u; r.px -= r.scale_f; }
-    if (cy <= tc_max) { step_mask ^= 2u; r.py -= r.scale_f; }
-    if (cz <= tc_max) { step_mask ^= 4u; r.pz -= r.scale_f; }
+    const bool sx = cx <= tc_max, sy = cy <= tc_max, sz = cz <= tc_max;   // :115-118
+    const uint32_t step_mask = (sx ? 1u : 0u) | (sy ? 2u : 0u) | (sz ? 4u : 0u);
+    r.px -= sx ? r.scale_f : 0.0f;     // x - 0 == x bit for bit
+    r.py -= sy ? r.scale_f : 0.0f;
+    r.pz -= sz ? r.scale_f : 0.0f;
     r.t_min = tc_max;                                                   // :120
     r.child_offset ^= step_mask;                                        // :121
     r.normal = step_mask;                                               // :122
@@ -234,7 +236,8 @@ __device__ __forceinline__ bool ray_step(Ray& r, const uint2* __restrict__ nodes
         // :137-143  (i >> scale) << scale == i & (~0 << scale); child bit = bit `scale` of i
         const uint32_t keep = 0xffffffffu << r.scale;
         r.px = u2f(ipx & keep); r.py = u2f(ipy & keep); r.pz = u2f(ipz & keep);
-        r.child_offset = ((ipx >> r.scale) & 1u) | (((ipy >> r.scale) & 1u) << 1u) | (((ipz >> r.scale) & 1u) << 2u);
+        r.child_offset = __builtin_amdgcn_ubfe(ipx, (uint32_t)r.scale, 1u) | (__builtin_amdgcn_ubfe(ipy, (uint32_t)r.scale, 1u) << 1u) |
+                         (__builtin_amdgcn_ubfe(ipz, (uint32_t)r.scale, 1u) << 2u);
         r.h = 0.0f;                                                      // :144
     }
     return true;
