@@ -16,9 +16,19 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
          "-fno-fast-math", "-Wall", "-Wno-unused-result"]
 
 
+STAMP = LIB + ".flags"   # the flags the library was built with: an experiment build is never mistaken for the product
+
+
+def _flag_line():
+    return " ".join(FLAGS + os.environ.get("VRC_EXTRA_FLAGS", "").split())
+
+
 def needs_build():
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(STAMP):
         return True
+    with open(STAMP) as f:
+        if f.read().strip() != _flag_line():
+            return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
@@ -33,6 +43,8 @@ def build_native(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    with open(STAMP, "w") as f:
+        f.write(_flag_line() + "\n")
     return LIB
 
 

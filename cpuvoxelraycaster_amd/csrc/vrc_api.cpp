@@ -11,6 +11,7 @@
 #include <cstring>
 
 #include "../../include/vrc.h"
+#include <vector>
 #include "vrc_internal.h"
 
 namespace {
@@ -58,7 +59,7 @@ struct vrc_renderer {
     uint32_t width, height;
     void* d_image;  // RGBA8
     void* d_accum;  // 4 x u32 per pixel
-    void* d_stats;  // 4 x u64 stats; work-queue heads: 8 x 128-byte lines from byte 128
+    void* d_stats;  // VRC_STATS_BYTES of counter slots, then VRC_QUEUE_BYTES of work-queue heads
     vrc_hit* d_prim;
 };
 
@@ -290,9 +291,9 @@ extern "C" int vrc_renderer_create(const vrc_scene* s, uint32_t width, uint32_t 
     const uint64_t n = (uint64_t)width * height;
     hipError_t e = hipMalloc(&r->d_image, n * 4);
     if (e == hipSuccess) e = hipMalloc(&r->d_accum, n * 16);
-    if (e == hipSuccess) e = hipMalloc(&r->d_stats, 2048);
+    if (e == hipSuccess) e = hipMalloc(&r->d_stats, vrc::VRC_STATS_BYTES + vrc::VRC_QUEUE_BYTES);
     if (e == hipSuccess) e = hipMemset(r->d_accum, 0, n * 16);
-    if (e == hipSuccess) e = hipMemset(r->d_stats, 0, 2048);
+    if (e == hipSuccess) e = hipMemset(r->d_stats, 0, vrc::VRC_STATS_BYTES + vrc::VRC_QUEUE_BYTES);
     if (e == hipSuccess) e = vrc::launch_fill_u32(r->d_image, 0xff000000u, n, nullptr);  // sf::Image::create: opaque black
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) {
@@ -344,7 +345,7 @@ extern "C" int vrc_render_frame(vrc_renderer* r, const vrc_camera* cam, const vr
     a.accum = (uint32_t*)r->d_accum;
     a.prim = r->d_prim;
     a.stats = (uint64_t*)r->d_stats;
-    a.queue = (uint32_t*)((uint8_t*)r->d_stats + 128);
+    a.queue = (uint32_t*)((uint8_t*)r->d_stats + vrc::VRC_STATS_BYTES);
     a.depth = s->depth; a.width = r->width; a.height = r->height;
     a.cam = *cam;
     a.p = *p;
@@ -365,7 +366,7 @@ extern "C" int vrc_render_frame(vrc_renderer* r, const vrc_camera* cam, const vr
     a.chunk = g_tuning.chunk;
     a.refill_threshold = g_tuning.refill_threshold;
     if (a.n_items == 0) return VRC_OK;
-    HIP_TRY(hipMemsetAsync(a.queue, 0, 8 * 128, st));
+    HIP_TRY(hipMemsetAsync(a.queue, 0, vrc::VRC_QUEUE_BYTES, st));
     uint64_t want = (items + VRC_RENDER_BLOCK - 1) / VRC_RENDER_BLOCK;
     // k_render_tile: (depth-1)*2 KiB of stacks + 21 KiB of job pools + 1.5 KiB of tables per workgroup
     // (38.5 KiB at depth 9): at most 4 fit a CU's 160 KiB; 120 VGPRs allow 4 waves per SIMD as well
@@ -386,11 +387,16 @@ extern "C" int vrc_render_frame(vrc_renderer* r, const vrc_camera* cam, const vr
     const uint32_t grid = (uint32_t)(want < cap ? want : cap);
     a.sample_chunk = 0;
     if (g_tuning.kernel == VRC_KERNEL_SYNC && a.p.use_samples && a.p.spp > 1) {
-        // keep >= ~4 work units per wave: split a pixel's samples over several units when tiles are few
+        // Units should be short against the launch (its end waits for the last unit of every wave, and the oldest
+        // wave of a SIMD runs ~3.6x faster than the youngest) yet not so small that the accumulator atomics and
+        // queue traffic show: the largest chunk that still gives ~48 units per wave, else 2 samples per unit,
+        // else (small multi-GPU shards) 1.  Measured: C3 1.91 -> 1.83 ms, C5 26.3 -> 26.0 ms (tools/chunk_time.py).
         const uint64_t tiles = a.n_items / 64, waves = (uint64_t)grid * (VRC_RENDER_BLOCK / 64);
         uint32_t c = g_tuning.sample_chunk ? g_tuning.sample_chunk : a.p.spp;
-        if (!g_tuning.sample_chunk)
-            while (c > 1 && tiles * ((a.p.spp + c - 1) / c) < 4 * waves) c = (c + 1) / 2;
+        if (!g_tuning.sample_chunk) {
+            while (c > 2 && tiles * ((a.p.spp + c - 1) / c) < 48 * waves) c = (c + 1) / 2;
+            if (c == 2 && tiles * ((a.p.spp + 1) / 2) < 12 * waves) c = 1;
+        }
         a.sample_chunk = c < a.p.spp ? c : 0;
     }
     HIP_TRY(vrc::launch_render(a, grid, (int)g_tuning.kernel, st));
@@ -455,12 +461,15 @@ extern "C" int vrc_get_stats(vrc_renderer* r, vrc_frame_stats* out, int reset, v
 {
     if (!r || !out) return fail(VRC_ERR_INVALID, "vrc_get_stats: null argument");
     HIP_TRY(hipSetDevice(r->scene->device));
-    uint64_t h[4];
-    HIP_TRY(hipMemcpyAsync(h, r->d_stats, 32, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    std::vector<uint64_t> slots(vrc::VRC_STAT_SLOTS * 4u);
+    HIP_TRY(hipMemcpyAsync(slots.data(), r->d_stats, vrc::VRC_STATS_BYTES, hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    uint64_t h[4] = {0, 0, 0, 0};
+    for (uint32_t i = 0; i < vrc::VRC_STAT_SLOTS; ++i)
+        for (int k = 0; k < 4; ++k) h[k] += slots[4u * i + k];
     out->rays = h[0]; out->sum_complexity = h[1]; out->primary_hits = h[2]; out->pixels = h[3];
     if (reset) {
-        HIP_TRY(hipMemsetAsync(r->d_stats, 0, 32, (hipStream_t)stream));
+        HIP_TRY(hipMemsetAsync(r->d_stats, 0, vrc::VRC_STATS_BYTES, (hipStream_t)stream));
         HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     }
     return VRC_OK;

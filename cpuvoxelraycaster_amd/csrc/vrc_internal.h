@@ -27,6 +27,14 @@ namespace vrc {
 int fail(int code, const char* fmt, ...);
 int require_device(int device, int* cu_count);
 
+// Counters and queue heads are spread out: thousands of waves ending within microseconds of each other on one
+// 128-byte line serialise in the L2 atomic unit (~88 atomics/us per line) and stretch the end of a launch.
+constexpr uint32_t VRC_STAT_SLOTS = 1024;      // 32-byte slots, slot = workgroup % VRC_STAT_SLOTS
+constexpr uint32_t VRC_QUEUE_HEADS = 8;
+constexpr uint32_t VRC_QUEUE_STRIDE = 1024;    // u32 between heads (4 KiB: separate L2 channels)
+constexpr uint32_t VRC_STATS_BYTES = VRC_STAT_SLOTS * 32u;
+constexpr uint32_t VRC_QUEUE_BYTES = VRC_QUEUE_HEADS * VRC_QUEUE_STRIDE * 4u;
+
 // by-value kernel argument of k_render
 struct FrameArgs {
     const uint2* nodes;       // LNode[] (8 B each)
@@ -34,8 +42,8 @@ struct FrameArgs {
     uint8_t* image;           // RGBA8 w*h
     uint32_t* accum;          // 4 x u32 per pixel
     vrc_hit* prim;            // optional primary-hit capture
-    uint64_t* stats;          // rays, sum_complexity, primary_hits, pixels
-    uint32_t* queue;          // work-queue head
+    uint64_t* stats;          // VRC_STAT_SLOTS x {rays, sum_complexity, primary_hits, pixels}; summed by vrc_get_stats
+    uint32_t* queue;          // work-queue heads, VRC_QUEUE_STRIDE u32 apart
     uint32_t depth, width, height;
     uint32_t n_items;         // work items (8x8-tile order over this shard's rows)
     uint32_t chunk;           // items a wave takes from the queue at once

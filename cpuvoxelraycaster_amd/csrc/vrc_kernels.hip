@@ -457,10 +457,11 @@ k_render(const FrameArgs a)
         s_pix += __shfl_down(s_pix, off);
     }
     if (__lane_id() == 0u) {
-        atomicAdd(reinterpret_cast<unsigned long long*>(a.stats + 0), (unsigned long long)s_rays);
-        atomicAdd(reinterpret_cast<unsigned long long*>(a.stats + 1), (unsigned long long)s_steps);
-        atomicAdd(reinterpret_cast<unsigned long long*>(a.stats + 2), (unsigned long long)s_hits);
-        atomicAdd(reinterpret_cast<unsigned long long*>(a.stats + 3), (unsigned long long)s_pix);
+        uint64_t* slot = a.stats + 4u * (blockIdx.x % VRC_STAT_SLOTS);
+        atomicAdd(reinterpret_cast<unsigned long long*>(slot + 0), (unsigned long long)s_rays);
+        atomicAdd(reinterpret_cast<unsigned long long*>(slot + 1), (unsigned long long)s_steps);
+        atomicAdd(reinterpret_cast<unsigned long long*>(slot + 2), (unsigned long long)s_hits);
+        atomicAdd(reinterpret_cast<unsigned long long*>(slot + 3), (unsigned long long)s_pix);
     }
 }
 
@@ -801,10 +802,11 @@ k_render_tile(const FrameArgs a)
         s_pix += __shfl_down(s_pix, off);
     }
     if (lane == 0u) {
-        atomicAdd(reinterpret_cast<unsigned long long*>(a.stats + 0), (unsigned long long)s_rays);
-        atomicAdd(reinterpret_cast<unsigned long long*>(a.stats + 1), (unsigned long long)s_steps);
-        atomicAdd(reinterpret_cast<unsigned long long*>(a.stats + 2), (unsigned long long)s_hits);
-        atomicAdd(reinterpret_cast<unsigned long long*>(a.stats + 3), (unsigned long long)s_pix);
+        uint64_t* slot = a.stats + 4u * (blockIdx.x % VRC_STAT_SLOTS);
+        atomicAdd(reinterpret_cast<unsigned long long*>(slot + 0), (unsigned long long)s_rays);
+        atomicAdd(reinterpret_cast<unsigned long long*>(slot + 1), (unsigned long long)s_steps);
+        atomicAdd(reinterpret_cast<unsigned long long*>(slot + 2), (unsigned long long)s_hits);
+        atomicAdd(reinterpret_cast<unsigned long long*>(slot + 3), (unsigned long long)s_pix);
     }
 }
 
@@ -825,6 +827,17 @@ k_render_tile(const FrameArgs a)
 
 #ifndef VRC_SYNC_MIN_WAVES
 #define VRC_SYNC_MIN_WAVES 5
+#endif
+
+#ifdef VRC_PROBE
+__device__ __forceinline__ uint32_t probe_wave_max(uint32_t v)
+{
+    for (int off = 32; off > 0; off >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, off));
+    return v;
+}
+#define VRC_PROBE_WALK(r, k) probe_c##k = (r).complexity;
+#else
+#define VRC_PROBE_WALK(r, k)
 #endif
 
 extern "C" __global__ void __launch_bounds__(VRC_RENDER_BLOCK, VRC_SYNC_MIN_WAVES)
@@ -866,17 +879,50 @@ k_render_sync(const FrameArgs a)
     // units are handed out whatever the placement.  One head saturates at ~88 dequeues/us, which a
     // small multi-GPU shard (16 k units in 0.3 ms) would hit.
     uint32_t head = blockIdx.x & 7u, heads_tried = 0u;
+#ifdef VRC_PROBE   // diagnostics build only: per-wave start / end wall clock (100 MHz) and unit count into the capture buffer
+    const uint64_t probe_t0 = wall_clock64();
+    uint32_t probe_units = 0u, probe_last_unit = 0xffffffffu, probe_longest_unit = 0u, probe_iters = 0u;
+    uint64_t probe_last_t0 = probe_t0, probe_longest = 0u;
+#endif
 
     for (;;) {
         uint32_t unit = 0u;
-        if (lane == 0u) unit = atomicAdd(a.queue + head * 32u, 1u);
+        if (lane == 0u) {
+            // after the first dry head, look before taking: a dry head then costs a load, not an atomic
+            uint32_t* q = a.queue + head * VRC_QUEUE_STRIDE;
+            unit = heads_tried ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            if (unit * 8u + head < n_units) unit = atomicAdd(q, 1u);
+        }
         unit = __builtin_amdgcn_readfirstlane(unit) * 8u + head;
         if (unit >= n_units) {
             if (++heads_tried == 8u) break;
             head = (head + 1u) & 7u;
             continue;
         }
+#ifdef VRC_PROBE
+        ++probe_units;
+        const uint64_t probe_t1 = wall_clock64();
+        const uint64_t probe_prev_t0 = probe_last_t0;
+        if (probe_t1 - probe_last_t0 > probe_longest) { probe_longest = probe_t1 - probe_last_t0; probe_longest_unit = probe_last_unit; }
+        probe_last_t0 = probe_t1;
+#endif
+#ifdef VRC_PROBE
+        {   // experiment: per-unit durations at +1 MiB, optional unit order table at +2 MiB (flag at +2 MiB - 4)
+            uint32_t* pb = reinterpret_cast<uint32_t*>(a.prim);
+            if (probe_last_unit != 0xffffffffu && lane == 0u) {
+                pb[(1u << 18) + probe_last_unit] = (uint32_t)(probe_t1 - probe_prev_t0);
+                pb[(3u << 18) + probe_last_unit] = probe_iters;
+            }
+            probe_iters = 0u;
+            if (pb[(1u << 19) - 1u]) unit = pb[(1u << 19) + unit];
+            probe_last_unit = unit;
+        }
+#endif
+#ifdef VRC_REVERSE
+        const uint32_t tile = n_tiles - 1u - unit / chunks_per_tile;
+#else
         const uint32_t tile = unit / chunks_per_tile;
+#endif
         const uint32_t s_begin = (unit % chunks_per_tile) * chunk, s_end = min(spp, s_begin + chunk);
         const uint32_t tx = tile % tiles_per_row, ty = tile / tiles_per_row;
         const uint32_t px_x = tx * 8u + (lane & 7u);
@@ -889,6 +935,9 @@ k_render_sync(const FrameArgs a)
         for (uint32_t sample = s_begin; sample < s_end; ++sample) {
             const uint32_t fr = a.p.frame_index + sample;
             uint32_t color = 0u;                                                 // ColorResult: Black
+#ifdef VRC_PROBE
+            uint32_t probe_c0 = 0u, probe_c1 = 0u, probe_c2 = 0u, probe_c3 = 0u;
+#endif
             if (valid) {
                 // R0: main.cpp:133,145-149; camera_controller.hpp:34-54
                 const float aspect_ratio = (float)W / (float)H;
@@ -915,15 +964,17 @@ k_render_sync(const FrameArgs a)
                 Ray r;
                 bool active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
                 while (active) active = ray_step<VRC_RENDER_BLOCK, false>(r, nodes, stk, depth, 0.0f, 0.0f);
-                n_rays += 1u; n_steps += r.complexity;
+                n_rays += 1u; n_steps += r.complexity; VRC_PROBE_WALK(r, 0)
                 Hit h;
                 ray_finish(r, depth, ox, oy, oz, dx, dy, dz, h);                   // raycaster.hpp:131
+#ifndef VRC_PROBE
                 if (a.prim && sample == 0u) {
                     uint4* o = reinterpret_cast<uint4*>(a.prim + pix);
                     o[0] = make_uint4(f2u(h.px), f2u(h.py), f2u(h.pz), f2u(h.nx));
                     o[1] = make_uint4(f2u(h.ny), f2u(h.nz), f2u(h.u), f2u(h.v));
                     o[2] = make_uint4(h.hit, h.node, f2u(h.distance), h.complexity);
                 }
+#endif
                 if (h.hit) {
                     n_hits += 1u;
                     // raycaster.hpp:209-240 albedo
@@ -943,7 +994,7 @@ k_render_sync(const FrameArgs a)
                         const float lit = smax(0.0f, dot3(dx, dy, dz, h.nx, h.ny, h.nz));       // :156
                         active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
                         while (active) active = ray_step<VRC_RENDER_BLOCK, false>(r, nodes, stk, depth, 0.0f, 0.0f);
-                        n_rays += 1u; n_steps += r.complexity;
+                        n_rays += 1u; n_steps += r.complexity; VRC_PROBE_WALK(r, 1)
                         if (!r.kind) light_intensity = lit;                                  // :155-157
                     }
                     // raycaster.hpp:161,169-207 GI (+ the nested second bounce of the extension)
@@ -972,7 +1023,7 @@ k_render_sync(const FrameArgs a)
                             if (level == 0u) dgi[0] = dot_gi; else dgi[1] = dot_gi;
                             active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
                             while (active) active = ray_step<VRC_RENDER_BLOCK>(r, nodes, stk, depth, 0.5f, 0.0f);   // :194
-                            n_rays += 1u; n_steps += r.complexity;
+                            n_rays += 1u; n_steps += r.complexity; VRC_PROBE_WALK(r, 2)
                             Hit g;
                             ray_finish(r, depth, ox, oy, oz, dx, dy, dz, g);
                             chain = false;
@@ -986,7 +1037,7 @@ k_render_sync(const FrameArgs a)
                                 const float contrib = 1000000.0f * smin(0.5f, smax(0.0f, dotl) * dot_gi);   // :201
                                 active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
                                 while (active) active = ray_step<VRC_RENDER_BLOCK>(r, nodes, stk, depth, 0.5f, 0.0f);   // :198
-                                n_rays += 1u; n_steps += r.complexity;
+                                n_rays += 1u; n_steps += r.complexity; VRC_PROBE_WALK(r, 3)
                                 if (!r.kind) { if (level == 0u) acc[0] += contrib; else acc[1] += contrib; }
                                 if (level + 1u < gi_bounces) {
                                     base_px = g.px; base_py = g.py; base_pz = g.pz;
@@ -1013,6 +1064,9 @@ k_render_sync(const FrameArgs a)
                     reinterpret_cast<uint32_t*>(a.image)[pix] = color_add_sat(old, nw) | alpha;
                 }
             }
+#ifdef VRC_PROBE
+            probe_iters += probe_wave_max(probe_c0) + probe_wave_max(probe_c1) + probe_wave_max(probe_c2) + probe_wave_max(probe_c3);
+#endif
         }
         if (valid && a.p.use_samples) {                                              // raycaster.hpp:87-90
             if (chunks_per_tile == 1u) {
@@ -1027,6 +1081,18 @@ k_render_sync(const FrameArgs a)
         }
     }
 
+#ifdef VRC_PROBE
+    if (a.prim && lane == 0u) {
+        uint64_t* o = reinterpret_cast<uint64_t*>(a.prim) + 8ull * (blockIdx.x * (VRC_RENDER_BLOCK / 64u) + (threadIdx.x >> 6));
+        o[0] = probe_t0; o[1] = wall_clock64(); o[2] = probe_units | ((uint64_t)probe_last_unit << 32);
+        if (probe_last_unit != 0xffffffffu) {
+            reinterpret_cast<uint32_t*>(a.prim)[(1u << 18) + probe_last_unit] = (uint32_t)(o[1] - probe_last_t0);
+            reinterpret_cast<uint32_t*>(a.prim)[(3u << 18) + probe_last_unit] = probe_iters;
+        }
+        o[3] = probe_last_t0; o[4] = probe_longest; o[5] = probe_longest_unit;
+        o[6] = __builtin_amdgcn_s_getreg((31 << 11) | 4); o[7] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    }
+#endif
     uint64_t s_rays = n_rays, s_steps = n_steps, s_hits = n_hits, s_pix = n_pix;
     for (int off = 32; off > 0; off >>= 1) {
         s_rays += __shfl_down(s_rays, off);
@@ -1035,10 +1101,11 @@ k_render_sync(const FrameArgs a)
         s_pix += __shfl_down(s_pix, off);
     }
     if (lane == 0u) {
-        atomicAdd(reinterpret_cast<unsigned long long*>(a.stats + 0), (unsigned long long)s_rays);
-        atomicAdd(reinterpret_cast<unsigned long long*>(a.stats + 1), (unsigned long long)s_steps);
-        atomicAdd(reinterpret_cast<unsigned long long*>(a.stats + 2), (unsigned long long)s_hits);
-        atomicAdd(reinterpret_cast<unsigned long long*>(a.stats + 3), (unsigned long long)s_pix);
+        uint64_t* slot = a.stats + 4u * (blockIdx.x % VRC_STAT_SLOTS);
+        atomicAdd(reinterpret_cast<unsigned long long*>(slot + 0), (unsigned long long)s_rays);
+        atomicAdd(reinterpret_cast<unsigned long long*>(slot + 1), (unsigned long long)s_steps);
+        atomicAdd(reinterpret_cast<unsigned long long*>(slot + 2), (unsigned long long)s_hits);
+        atomicAdd(reinterpret_cast<unsigned long long*>(slot + 3), (unsigned long long)s_pix);
     }
 }
 
