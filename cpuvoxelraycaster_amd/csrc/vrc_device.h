@@ -243,6 +243,23 @@ __device__ __forceinline__ bool ray_step(Ray& r, const uint2* __restrict__ nodes
     return true;
 }
 
+}  // namespace vrc
+#include "vrc_walk.h"
+namespace vrc {
+
+// The whole walk of one ray.  LOD_MODE: 0 = coef == bias == 0 (primary / shadow rays), 1 = bias == 0, 2 = general.
+template <int STRIDE, int LOD_MODE>
+__device__ __forceinline__ void ray_run(Ray& r, bool active, const uint2* __restrict__ nodes, uint2* stk,
+                                        int depth, float coef, float bias)
+{
+#ifdef VRC_WALK_CPP
+    while (active) active = ray_step<STRIDE, LOD_MODE != 0>(r, nodes, stk, depth, coef, bias);
+#else
+    static_assert(STRIDE == 256, "vrc_walk.h addresses LDS stack rows of 256 lanes");
+    ray_walk<LOD_MODE>(r, active, nodes, stk, depth, coef, bias);
+#endif
+}
+
 struct Hit {
     float px, py, pz;     // position
     float nx, ny, nz;     // normal

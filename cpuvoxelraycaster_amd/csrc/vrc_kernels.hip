@@ -47,7 +47,7 @@ __device__ __forceinline__ void cast_rays_body(const uint2* __restrict__ nodes, 
     Ray r;
     bool active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
     uint2* stk = lds_stack + threadIdx.x;
-    while (active) active = ray_step<256, LOD>(r, nodes, stk, depth, coef, bias);
+    ray_run<256, LOD ? 2 : 0>(r, active, nodes, stk, depth, coef, bias);
     Hit h;
     ray_finish(r, depth, ox, oy, oz, dx, dy, dz, h);
     // 48-byte record as three 16-byte stores
@@ -597,7 +597,7 @@ k_render_tile(const FrameArgs a)
                     float oz = (a.cam.position[2] + wz) * inv_size + 1.0f;
                     Ray r;
                     bool active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
-                    while (active) active = ray_step<VRC_RENDER_BLOCK, false>(r, nodes, stk, depth, 0.0f, 0.0f);
+                    ray_run<VRC_RENDER_BLOCK, 0>(r, active, nodes, stk, depth, 0.0f, 0.0f);
                     n_rays += 1u; n_steps += r.complexity;
                     ray_finish(r, depth, ox, oy, oz, dx, dy, dz, h);               // raycaster.hpp:131
                     if (a.prim && sample == 0u) {
@@ -624,7 +624,7 @@ k_render_tile(const FrameArgs a)
                             normalize3(dx, dy, dz);
                             const float lit = smax(0.0f, dot3(dx, dy, dz, h.nx, h.ny, h.nz));   // :156
                             active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
-                            while (active) active = ray_step<VRC_RENDER_BLOCK, false>(r, nodes, stk, depth, 0.0f, 0.0f);
+                            ray_run<VRC_RENDER_BLOCK, 0>(r, active, nodes, stk, depth, 0.0f, 0.0f);
                             n_rays += 1u; n_steps += r.complexity;
                             if (!r.kind) light_intensity = lit;                              // :155-157
                         }
@@ -963,7 +963,7 @@ k_render_sync(const FrameArgs a)
                 float oz = (a.cam.position[2] + wz) * inv_size + 1.0f;
                 Ray r;
                 bool active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
-                while (active) active = ray_step<VRC_RENDER_BLOCK, false>(r, nodes, stk, depth, 0.0f, 0.0f);
+                ray_run<VRC_RENDER_BLOCK, 0>(r, active, nodes, stk, depth, 0.0f, 0.0f);
                 n_rays += 1u; n_steps += r.complexity; VRC_PROBE_WALK(r, 0)
                 Hit h;
                 ray_finish(r, depth, ox, oy, oz, dx, dy, dz, h);                   // raycaster.hpp:131
@@ -993,7 +993,7 @@ k_render_sync(const FrameArgs a)
                         normalize3(dx, dy, dz);
                         const float lit = smax(0.0f, dot3(dx, dy, dz, h.nx, h.ny, h.nz));       // :156
                         active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
-                        while (active) active = ray_step<VRC_RENDER_BLOCK, false>(r, nodes, stk, depth, 0.0f, 0.0f);
+                        ray_run<VRC_RENDER_BLOCK, 0>(r, active, nodes, stk, depth, 0.0f, 0.0f);
                         n_rays += 1u; n_steps += r.complexity; VRC_PROBE_WALK(r, 1)
                         if (!r.kind) light_intensity = lit;                                  // :155-157
                     }
@@ -1022,7 +1022,7 @@ k_render_sync(const FrameArgs a)
                             const float dot_gi = dot3(dx, dy, dz, base_nx, base_ny, base_nz);   // :193
                             if (level == 0u) dgi[0] = dot_gi; else dgi[1] = dot_gi;
                             active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
-                            while (active) active = ray_step<VRC_RENDER_BLOCK>(r, nodes, stk, depth, 0.5f, 0.0f);   // :194
+                            ray_run<VRC_RENDER_BLOCK, 1>(r, active, nodes, stk, depth, 0.5f, 0.0f);   // :194
                             n_rays += 1u; n_steps += r.complexity; VRC_PROBE_WALK(r, 2)
                             Hit g;
                             ray_finish(r, depth, ox, oy, oz, dx, dy, dz, g);
@@ -1036,7 +1036,7 @@ k_render_sync(const FrameArgs a)
                                 const float dotl = dot3(g.nx, g.ny, g.nz, dx, dy, dz);         // :200
                                 const float contrib = 1000000.0f * smin(0.5f, smax(0.0f, dotl) * dot_gi);   // :201
                                 active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
-                                while (active) active = ray_step<VRC_RENDER_BLOCK>(r, nodes, stk, depth, 0.5f, 0.0f);   // :198
+                                ray_run<VRC_RENDER_BLOCK, 1>(r, active, nodes, stk, depth, 0.5f, 0.0f);   // :198
                                 n_rays += 1u; n_steps += r.complexity; VRC_PROBE_WALK(r, 3)
                                 if (!r.kind) { if (level == 0u) acc[0] += contrib; else acc[1] += contrib; }
                                 if (level + 1u < gi_bounces) {
