@@ -99,13 +99,12 @@ namespace vrc {
     "v_cmp_gt_f32_e64 %[sb], v51, v41\n"                                                        \
     "v_cmp_gt_f32_e32 vcc, v53, v41\n"                                                          \
     "v_add_u32_e32 %[scale], -1, %[scale]\n"    /* :104 */                                      \
-    "v_cndmask_b32_e64 %[t], 0, 1, %[sa]\n"                                                     \
-    "v_cndmask_b32_e64 %[t2], 0, 2, %[sb]\n"                                                    \
-    "v_cndmask_b32_e64 %[co], 0, 4, vcc\n"                                                      \
+    "v_cndmask_b32_e64 %[co], 0, 1, vcc\n"      /* child = z*4 + y*2 + x: n = 2n + bit by add-with-carry */ \
     "v_cndmask_b32_e64 v50, 0, v44, %[sa]\n"                                                    \
+    "v_addc_co_u32_e64 %[co], %[st], %[co], %[co], %[sb]\n"                                     \
     "v_cndmask_b32_e64 v51, 0, v44, %[sb]\n"                                                    \
     "v_cndmask_b32_e32 v53, 0, v44, vcc\n"                                                      \
-    "v_or3_b32 %[co], %[co], %[t], %[t2]\n"                                                     \
+    "v_addc_co_u32_e64 %[co], %[st], %[co], %[co], %[sa]\n"                                     \
     "v_pk_add_f32 v[38:39], v[38:39], v[50:51]\n"                                               \
     "v_add_f32_e32 v40, v40, v53\n"                                                             \
     /* ---- advance :113-122 ---- */                                                            \
@@ -116,13 +115,12 @@ namespace vrc {
     "v_cmp_le_f32_e64 %[sb], v49, %[tc]\n"                                                      \
     "v_cmp_le_f32_e32 vcc, v52, %[tc]\n"                                                        \
     "v_mov_b32_e32 v41, %[tc]\n"                /* :120 */                                      \
-    "v_cndmask_b32_e64 %[t], 0, 1, %[sa]\n"                                                     \
-    "v_cndmask_b32_e64 %[t2], 0, 2, %[sb]\n"                                                    \
-    "v_cndmask_b32_e64 %[normal], 0, 4, vcc\n"                                                  \
+    "v_cndmask_b32_e64 %[normal], 0, 1, vcc\n"                                                  \
     "v_cndmask_b32_e64 v50, 0, v44, %[sa]\n"                                                    \
+    "v_addc_co_u32_e64 %[normal], %[st], %[normal], %[normal], %[sb]\n"                         \
     "v_cndmask_b32_e64 v51, 0, v44, %[sb]\n"                                                    \
     "v_cndmask_b32_e32 v53, 0, v44, vcc\n"                                                      \
-    "v_or3_b32 %[normal], %[normal], %[t], %[t2]\n"   /* :122 */                                \
+    "v_addc_co_u32_e64 %[normal], %[st], %[normal], %[normal], %[sa]\n"   /* :122 */            \
     "v_pk_add_f32 v[38:39], v[38:39], v[50:51] neg_lo:[0,1] neg_hi:[0,1]\n"                     \
     "v_sub_f32_e32 v40, v40, v53\n"                                                             \
     "v_xor_b32_e32 %[co], %[co], %[normal]\n"   /* :121 */                                      \
