@@ -133,6 +133,9 @@ extern "C" int vrc_scene_create(const vrc_lnode* lnodes, uint64_t n_nodes, uint3
     hipError_t e = hipMalloc(&s->d_nodes, n_nodes * sizeof(vrc_lnode));
     if (e == hipSuccess) e = hipMalloc(&s->d_tex, 1536);
     if (e == hipSuccess) e = hipMemcpy(s->d_nodes, lnodes, n_nodes * sizeof(vrc_lnode), hipMemcpyHostToDevice);
+    // stray leaf bits (leaf without child: never read by the walk) are cleared in the device copy, see k_sanitize_nodes
+    if (e == hipSuccess) e = vrc::launch_sanitize_nodes(s->d_nodes, n_nodes, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e == hipSuccess) e = hipMemset(s->d_tex, 0xff, 1536);  // sf::Color::White until textures are set
     if (e != hipSuccess) {
         if (s->d_nodes) (void)hipFree(s->d_nodes);

@@ -63,6 +63,7 @@ uint32_t sync_max_blocks_per_cu();    // ... of k_render_sync
 hipError_t launch_render(const FrameArgs& a, uint32_t grid_blocks, int kernel, hipStream_t st);
 hipError_t launch_resolve(const void* accum, void* image, uint32_t n, hipStream_t st);
 hipError_t launch_fill_u32(void* p, uint32_t value, uint64_t n, hipStream_t st);
+hipError_t launch_sanitize_nodes(void* nodes, uint64_t n, hipStream_t st);   // leaf_mask &= child_mask
 hipError_t launch_pack_shard(const void* image, uint32_t W, uint32_t H, uint32_t row_block, uint32_t shard,
                              uint32_t count, uint32_t slots, void* dst, hipStream_t st);
 hipError_t launch_unpack_shards(const void* gathered, uint32_t W, uint32_t H, uint32_t row_block, uint32_t count,

@@ -1130,6 +1130,18 @@ extern "C" __global__ void k_fill_u32(uint32_t* __restrict__ p, uint32_t value, 
     if (i < n) p[i] = value;
 }
 
+// Scene upload: leaf_mask &= child_mask.  The walk looks at a leaf bit only when the child bit is set
+// (lsvo.hpp:81,90), so clearing stray leaf bits changes no result; it lets vrc_walk.h test both bits
+// with one AND.  compileSVO output (and both builders here) already has leaf_mask a subset of child_mask.
+extern "C" __global__ void k_sanitize_nodes(uint2* __restrict__ nodes, uint64_t n)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t x = nodes[i].x;
+    const uint32_t y = x & (0xff00ffffu | ((x & 0xff00u) << 8));
+    if (y != x) nodes[i].x = y;
+}
+
 // compact the row blocks owned by `shard` into dst: slot k <- block shard + k*count
 extern "C" __global__ void k_pack_shard(const uint32_t* __restrict__ image, uint32_t W, uint32_t H, uint32_t row_block,
                                         uint32_t shard, uint32_t count, uint32_t slots, uint32_t* __restrict__ dst)
@@ -1216,6 +1228,13 @@ hipError_t launch_fill_u32(void* p, uint32_t value, uint64_t n, hipStream_t st)
 {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_fill_u32, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, (uint32_t*)p, value, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_sanitize_nodes(void* nodes, uint64_t n, hipStream_t st)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_sanitize_nodes, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, (uint2*)nodes, n);
     return hipGetLastError();
 }
 

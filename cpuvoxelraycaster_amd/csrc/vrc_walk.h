@@ -25,16 +25,16 @@ namespace vrc {
 // 2 = general.
 #define VRC_WALK_LOD_NONE ""
 #define VRC_WALK_LOD_COEF                                                                       \
-    "v_mul_f32_e32 %[t], %[coef], %[tc]\n"                                                      \
-    "v_cmp_ge_f32_e32 vcc, %[t], v44\n"                                                         \
+    "v_mul_f32_e32 %[t2], %[coef], %[tc]\n"                                                     \
+    "v_cmp_ge_f32_e32 vcc, %[t2], v44\n"                                                         \
     "s_and_b64 %[st], %[stm], vcc\n"            /* child && t_min <= t_max && tc*coef >= scale_f */ \
     "s_or_b64 %[slod], %[slod], %[st]\n"                                                        \
     "s_andn2_b64 %[sin], %[sin], %[st]\n"                                                       \
     "s_andn2_b64 exec, exec, %[st]\n"
 #define VRC_WALK_LOD_FULL                                                                       \
-    "v_mul_f32_e32 %[t], %[coef], %[tc]\n"                                                      \
-    "v_add_f32_e32 %[t], %[t], %[bias]\n"                                                       \
-    "v_cmp_ge_f32_e32 vcc, %[t], v44\n"                                                         \
+    "v_mul_f32_e32 %[t2], %[coef], %[tc]\n"                                                     \
+    "v_add_f32_e32 %[t2], %[t2], %[bias]\n"                                                     \
+    "v_cmp_ge_f32_e32 vcc, %[t2], v44\n"                                                         \
     "s_and_b64 %[st], %[stm], vcc\n"                                                            \
     "s_or_b64 %[slod], %[slod], %[st]\n"                                                        \
     "s_andn2_b64 %[sin], %[sin], %[st]\n"                                                       \
@@ -61,7 +61,7 @@ namespace vrc {
     "v_lshrrev_b32_e32 %[m], %[cs], v46\n"      /* bit 8: child, bit 16: leaf */                \
     "v_pk_add_f32 v[48:49], v[48:49], v[36:37] neg_lo:[0,1] neg_hi:[0,1]\n"                     \
     "v_sub_f32_e32 v52, v52, v35\n"                                                             \
-    "v_and_b32_e32 %[t], 0x100, %[m]\n"                                                         \
+    "v_and_b32_e32 %[t], 0x10100, %[m]\n"       /* leaf_mask is a subset of child_mask (k_sanitize_nodes): 0, 0x100 or 0x10100 */ \
     "v_min3_f32 %[tc], v48, v49, v52\n"         /* :77 */                                       \
     "v_cmp_ne_u32_e64 %[schild], 0, %[t]\n"                                                     \
     "v_cmp_le_f32_e32 vcc, v41, v43\n"          /* :81 t_min <= t_max */                        \
@@ -69,8 +69,7 @@ namespace vrc {
     "v_cmp_le_f32_e32 vcc, v41, %[tc]\n"        /* with the line above: t_min <= min(t_max, tc), :86,:89 */ \
     "s_and_b64 %[sin], %[stm], vcc\n"                                                           \
     LODPART                                                                                     \
-    "v_and_b32_e32 %[t], 0x10000, %[m]\n"                                                       \
-    "v_cmp_ne_u32_e32 vcc, 0, %[t]\n"                                                           \
+    "v_cmp_lt_u32_e32 vcc, 0x100, %[t]\n"       /* child and leaf */                            \
     "s_and_b64 %[st], %[sin], vcc\n"            /* leaf hit :90-94 */                           \
     "s_or_b64 %[sleaf], %[sleaf], %[st]\n"                                                      \
     "s_andn2_b64 %[sin], %[sin], %[st]\n"       /* lanes that descend */                        \

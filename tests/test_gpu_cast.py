@@ -223,3 +223,22 @@ def test_argument_validation(built):
         rc.renderFrame(vrc.make_camera((4, 4, 4), vrc.make_rotation(0, 0)))
     with pytest.raises(vrc.VrcError):
         vrc.RayCaster(svo, (0, 8))
+
+
+def test_stray_leaf_bits_are_ignored(built, heights):
+    """A leaf bit without its child bit is never read by the reference (lsvo.hpp:81,90).  The device copy clears
+    such bits at upload (k_sanitize_nodes) so that the walk can test both masks at once: results must equal the
+    oracle's on the unmodified array, with and without the LOD cut-off."""
+    import cpuvoxelraycaster_amd as vrc
+    nodes = vrc.build_terrain_lsvo(heights, 7).copy()
+    rng = np.random.default_rng(5)
+    stray = rng.integers(0, 256, len(nodes)).astype(np.uint8) & ~nodes["child_mask"]
+    assert stray.any()
+    nodes["leaf_mask"] |= stray
+    svo = vrc.LSVO(nodes, 7)
+    org, d = raygen.mixed_rays(100000, seed=3)
+    assert_hits_equal(svo.castRays(org, d), O.cast_rays(nodes, 7, org, d, threads=8))
+    assert_hits_equal(svo.castRays(org, d, coef=0.5, bias=0.0), O.cast_rays(nodes, 7, org, d, coef=0.5, bias=0.0, threads=8))
+    back = svo.downloadNodes()
+    assert np.array_equal(back["leaf_mask"], nodes["leaf_mask"] & nodes["child_mask"])
+    assert np.array_equal(back["child_mask"], nodes["child_mask"]) and np.array_equal(back["child_offset"], nodes["child_offset"])
