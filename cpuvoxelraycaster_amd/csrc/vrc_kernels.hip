@@ -826,7 +826,7 @@ k_render_tile(const FrameArgs a)
 // code executed at partial utilisation and in occupancy.
 
 #ifndef VRC_SYNC_MIN_WAVES
-#define VRC_SYNC_MIN_WAVES 5
+#define VRC_SYNC_MIN_WAVES 6
 #endif
 
 #ifdef VRC_PROBE
