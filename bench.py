@@ -155,7 +155,9 @@ def main():
         state["pending"] = None
 
     def step(timed):
-        rc.resetSamples(stream)
+        # one frame = render (spp samples per pixel into the accumulators) + one pass that resolves this rank's
+        # rows to RGBA8 (straight into the packed shard buffer for N > 1) and clears their accumulators for the
+        # next frame (vrc_resolve_shard = samples_to_image + pack_shard + reset_samples)
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -164,12 +166,11 @@ def main():
         else:
             rc.renderFrame(cam, spp=spp, stream=stream)
         e1.record()
-        rc.samples_to_image(stream)
         if world > 1:
             slot = state["i"] % 2
-            rc.packShard(ROW_BLOCK, rank, world, mine[slot].data_ptr(), stream)
+            rc.resolveShard(ROW_BLOCK, rank, world, mine[slot].data_ptr(), reset=True, stream=stream)
             if backend == "nccl":
-                # RCCL over xGMI: RGBA8 row-block shards; enqueued behind the pack, runs beside the next render
+                # RCCL over xGMI: RGBA8 row-block shards; enqueued behind the resolve, runs beside the next render
                 work = dist.all_gather_into_tensor(gathered[slot], mine[slot], async_op=True)
             else:
                 torch.cuda.current_stream().synchronize()
@@ -180,9 +181,12 @@ def main():
             finish_gather()                                    # previous frame's gather -> full frame
             state["pending"] = (work, slot)
             state["i"] += 1
+        else:
+            rc.resolveShard(reset=True, stream=stream)
         if timed:
             ev_pairs.append((e0, e1))
 
+    rc.resetSamples(stream)
     for _ in range(args.warmup):
         step(False)
     if world > 1:

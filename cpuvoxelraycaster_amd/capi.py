@@ -83,6 +83,7 @@ SYMBOLS = {
     "vrc_get_stats": (_int, [_vp, C.POINTER(FrameStats), _int, _vp]),
     "vrc_shard_bytes": (_u64, [_u32, _u32, _u32, _u32]),
     "vrc_pack_shard": (_int, [_vp, _u32, _u32, _u32, _vp, _vp]),
+    "vrc_resolve_shard": (_int, [_vp, _u32, _u32, _u32, _vp, _int, _vp]),
     "vrc_unpack_shards": (_int, [_vp, _u32, _u32, _u32, _u32, _vp, _vp]),
     "vrc_make_rotation": (None, [_f32, _f32, _vp]),
     "vrc_set_tuning": (_int, [_u32, _u32, _u32]),

@@ -61,6 +61,7 @@ struct vrc_renderer {
     void* d_accum;  // 4 x u32 per pixel
     void* d_stats;  // VRC_STATS_BYTES of counter slots, then VRC_QUEUE_BYTES of work-queue heads
     vrc_hit* d_prim;
+    bool queue_clean;   // the heads were zeroed by vrc_resolve_shard(reset) after the last frame launch
 };
 
 extern "C" const char* vrc_last_error(void) { return g_err; }
@@ -369,7 +370,8 @@ extern "C" int vrc_render_frame(vrc_renderer* r, const vrc_camera* cam, const vr
     a.chunk = g_tuning.chunk;
     a.refill_threshold = g_tuning.refill_threshold;
     if (a.n_items == 0) return VRC_OK;
-    HIP_TRY(hipMemsetAsync(a.queue, 0, vrc::VRC_QUEUE_BYTES, st));
+    if (!r->queue_clean) HIP_TRY(hipMemsetAsync(a.queue, 0, vrc::VRC_QUEUE_BYTES, st));
+    r->queue_clean = false;
     uint64_t want = (items + VRC_RENDER_BLOCK - 1) / VRC_RENDER_BLOCK;
     // k_render_tile: (depth-1)*2 KiB of stacks + 21 KiB of job pools + 1.5 KiB of tables per workgroup
     // (38.5 KiB at depth 9): at most 4 fit a CU's 160 KiB; 120 VGPRs allow 4 waves per SIMD as well
@@ -387,21 +389,25 @@ extern "C" int vrc_render_frame(vrc_renderer* r, const vrc_camera* cam, const vr
         if (bpc > fit) bpc = fit;
     }
     const uint64_t cap = (uint64_t)s->cu_count * bpc;
-    const uint32_t grid = (uint32_t)(want < cap ? want : cap);
     a.sample_chunk = 0;
     if (g_tuning.kernel == VRC_KERNEL_SYNC && a.p.use_samples && a.p.spp > 1) {
         // Units should be short against the launch (its end waits for the last unit of every wave, and the oldest
         // wave of a SIMD runs ~3.6x faster than the youngest) yet not so small that the accumulator atomics and
-        // queue traffic show: the largest chunk that still gives ~48 units per wave, else 2 samples per unit,
-        // else (small multi-GPU shards) 1.  Measured: C3 1.91 -> 1.83 ms, C5 26.3 -> 26.0 ms (tools/chunk_time.py).
-        const uint64_t tiles = a.n_items / 64, waves = (uint64_t)grid * (VRC_RENDER_BLOCK / 64);
+        // queue traffic show: the largest chunk that still gives ~48 units per wave of a full grid, else 2 samples
+        // per unit, else (small multi-GPU shards) 1.  Measured: C3 1.91 -> 1.83 ms, C5 26.3 -> 26.0 ms
+        // (tools/chunk_time.py).
+        const uint64_t tiles = a.n_items / 64, waves = cap * (VRC_RENDER_BLOCK / 64);
         uint32_t c = g_tuning.sample_chunk ? g_tuning.sample_chunk : a.p.spp;
         if (!g_tuning.sample_chunk) {
             while (c > 2 && tiles * ((a.p.spp + c - 1) / c) < 48 * waves) c = (c + 1) / 2;
             if (c == 2 && tiles * ((a.p.spp + 1) / 2) < 12 * waves) c = 1;
         }
         a.sample_chunk = c < a.p.spp ? c : 0;
+        // one wave per unit until the chip is full: a shard of few tiles still spreads over all CUs
+        const uint64_t units = tiles * ((a.p.spp + c - 1) / c);
+        want = (units + VRC_RENDER_BLOCK / 64 - 1) / (VRC_RENDER_BLOCK / 64);
     }
+    const uint32_t grid = (uint32_t)(want < cap ? want : cap);
     HIP_TRY(vrc::launch_render(a, grid, (int)g_tuning.kernel, st));
     return VRC_OK;
 }
@@ -502,6 +508,21 @@ extern "C" int vrc_pack_shard(vrc_renderer* r, uint32_t row_block, uint32_t shar
     HIP_TRY(hipSetDevice(r->scene->device));
     HIP_TRY(vrc::launch_pack_shard(r->d_image, r->width, r->height, row_block, shard_index, shard_count,
                                    shard_slots(r->height, row_block, shard_count), dst_dev, (hipStream_t)stream));
+    return VRC_OK;
+}
+
+extern "C" int vrc_resolve_shard(vrc_renderer* r, uint32_t row_block, uint32_t shard_index, uint32_t shard_count, void* dst_dev,
+                                 int reset, void* stream)
+{
+    if (!r || !shard_count || shard_index >= shard_count) return fail(VRC_ERR_INVALID, "vrc_resolve_shard: bad argument");
+    if (shard_count == 1 && row_block == 0) row_block = r->height;     // the whole frame as one block
+    if (!row_block) return fail(VRC_ERR_INVALID, "vrc_resolve_shard: row_block is 0");
+    HIP_TRY(hipSetDevice(r->scene->device));
+    uint32_t* queue = (uint32_t*)((uint8_t*)r->d_stats + vrc::VRC_STATS_BYTES);
+    HIP_TRY(vrc::launch_resolve_shard(r->d_accum, r->d_image, r->width, r->height, row_block, shard_index, shard_count,
+                                      shard_slots(r->height, row_block, shard_count), dst_dev, reset ? 1u : 0u, queue,
+                                      (hipStream_t)stream));
+    if (reset) r->queue_clean = true;
     return VRC_OK;
 }
 

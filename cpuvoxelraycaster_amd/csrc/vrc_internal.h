@@ -66,6 +66,8 @@ hipError_t launch_fill_u32(void* p, uint32_t value, uint64_t n, hipStream_t st);
 hipError_t launch_sanitize_nodes(void* nodes, uint64_t n, hipStream_t st);   // leaf_mask &= child_mask
 hipError_t launch_pack_shard(const void* image, uint32_t W, uint32_t H, uint32_t row_block, uint32_t shard,
                              uint32_t count, uint32_t slots, void* dst, hipStream_t st);
+hipError_t launch_resolve_shard(void* accum, void* image, uint32_t W, uint32_t H, uint32_t row_block, uint32_t shard,
+                                uint32_t count, uint32_t slots, void* dst, uint32_t reset, uint32_t* queue, hipStream_t st);
 hipError_t launch_unpack_shards(const void* gathered, uint32_t W, uint32_t H, uint32_t row_block, uint32_t count,
                                 uint32_t slots, void* image, hipStream_t st);
 

@@ -10,7 +10,7 @@
 //                   primary -> shadow -> GI -> GI-shadow state machine over ONE shared traversal loop
 //                   and is refilled from a global work queue
 //   k_grid_cast     G1   Grid3D::castRay (grid_3d.hpp:36-132)
-//   k_resolve / k_fill_u32 / k_pack_shard / k_unpack_shards   S4 sink + multi-GPU shard plumbing
+//   k_resolve / k_resolve_shard / k_fill_u32 / k_pack_shard / k_unpack_shards   S4 sink + multi-GPU shard plumbing
 //
 // The three frame kernels produce bit-identical results (DESIGN.md section 4 has the measurements).
 // No MFMA anywhere: this is dependent 8-byte gathers, not a contraction.
@@ -1156,6 +1156,32 @@ extern "C" __global__ void k_pack_shard(const uint32_t* __restrict__ image, uint
     dst[i] = (y < H) ? image[(uint64_t)y * W + x] : 0u;
 }
 
+// k_resolve + k_pack_shard (+ the reset of the accumulators and of the work-queue heads) in one pass over the
+// shard's own row blocks: a multi-GPU frame is then render -> this -> all-gather -> unpack.
+extern "C" __global__ void k_resolve_shard(uint4* __restrict__ accum, uint32_t* __restrict__ image, uint32_t W, uint32_t H,
+                                           uint32_t row_block, uint32_t shard, uint32_t count, uint32_t slots,
+                                           uint32_t* __restrict__ dst, uint32_t reset, uint32_t* __restrict__ queue)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (reset && blockIdx.x == 0 && threadIdx.x < VRC_QUEUE_HEADS) queue[threadIdx.x * VRC_QUEUE_STRIDE] = 0u;
+    const uint64_t per_slot = (uint64_t)row_block * W;
+    if (i >= per_slot * slots) return;
+    const uint32_t k = (uint32_t)(i / per_slot);
+    const uint64_t rem = i % per_slot;
+    const uint32_t y = (k * count + shard) * row_block + (uint32_t)(rem / W);
+    const uint32_t x = (uint32_t)(rem % W);
+    uint32_t c = 0u;
+    if (y < H) {
+        const uint64_t p = (uint64_t)y * W + x;
+        const uint4 v = accum[p];
+        if (v.w) c = (v.x / v.w) | ((v.y / v.w) << 8) | ((v.z / v.w) << 16);   // raycaster.hpp:94-103
+        c |= 0xff000000u;
+        image[p] = c;
+        if (reset) accum[p] = make_uint4(0u, 0u, 0u, 0u);                      // raycaster.hpp:105-116
+    }
+    if (dst) dst[i] = c;
+}
+
 // inverse: gathered[shard][slot][row_block][W] -> image
 extern "C" __global__ void k_unpack_shards(const uint32_t* __restrict__ gathered, uint32_t W, uint32_t H, uint32_t row_block,
                                            uint32_t count, uint32_t slots, uint32_t* __restrict__ image)
@@ -1245,6 +1271,16 @@ hipError_t launch_pack_shard(const void* image, uint32_t W, uint32_t H, uint32_t
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_pack_shard, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st,
                        (const uint32_t*)image, W, H, row_block, shard, count, slots, (uint32_t*)dst);
+    return hipGetLastError();
+}
+
+hipError_t launch_resolve_shard(void* accum, void* image, uint32_t W, uint32_t H, uint32_t row_block, uint32_t shard,
+                                uint32_t count, uint32_t slots, void* dst, uint32_t reset, uint32_t* queue, hipStream_t st)
+{
+    const uint64_t n = (uint64_t)row_block * W * slots;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_resolve_shard, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, (uint4*)accum, (uint32_t*)image,
+                       W, H, row_block, shard, count, slots, (uint32_t*)dst, reset, queue);
     return hipGetLastError();
 }
 

@@ -235,6 +235,10 @@ class RayCaster:
     def packShard(self, row_block, shard_index, shard_count, dst_ptr, stream=None):
         check(capi.load().vrc_pack_shard(self._h, row_block, shard_index, shard_count, ptr(dst_ptr), ptr(stream)))
 
+    def resolveShard(self, row_block=0, shard_index=0, shard_count=1, dst_ptr=None, reset=False, stream=None):
+        """samples_to_image (+ packShard, + resetSamples) for this shard's rows in one kernel."""
+        check(capi.load().vrc_resolve_shard(self._h, row_block, shard_index, shard_count, ptr(dst_ptr), int(reset), ptr(stream)))
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
             capi.load().vrc_renderer_destroy(self._h)

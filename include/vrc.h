@@ -208,6 +208,13 @@ int vrc_get_stats(vrc_renderer *r, vrc_frame_stats *out, int reset, void *stream
 uint64_t vrc_shard_bytes(uint32_t width, uint32_t height, uint32_t row_block, uint32_t shard_count);
 int vrc_pack_shard(vrc_renderer *r, uint32_t row_block, uint32_t shard_index, uint32_t shard_count,
                    void *dst_dev, void *stream);
+/* vrc_samples_to_image + vrc_pack_shard (+ vrc_reset_samples when `reset` != 0) for this shard's row blocks in
+ * one pass: resolves the accumulators of the shard's pixels into the image and, when dst_dev != NULL, into the
+ * packed shard buffer; with `reset` the same pixels' accumulators are zeroed for the next frame (a following
+ * vrc_render_frame must be ordered after this call, as it would after vrc_reset_samples).
+ * shard_count == 1 with row_block == 0 covers the whole frame (dst_dev layout == image layout). */
+int vrc_resolve_shard(vrc_renderer *r, uint32_t row_block, uint32_t shard_index, uint32_t shard_count,
+                      void *dst_dev, int reset, void *stream);
 int vrc_unpack_shards(const void *gathered_dev, uint32_t width, uint32_t height, uint32_t row_block,
                       uint32_t shard_count, void *image_dev, void *stream);
 

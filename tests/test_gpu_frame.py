@@ -160,6 +160,57 @@ def test_sharded_frames_compose(scene, textures):
     assert total_rays == full.stats().rays
 
 
+def test_resolve_shard_equals_resolve_pack_reset(scene, textures):
+    """vrc_resolve_shard = samples_to_image + pack_shard (+ reset_samples) in one pass: same shard bytes, same image
+    rows, accumulators of the shard's rows cleared and nobody else's, and two frames in a row through it (the
+    work-queue heads are reset by the same kernel) equal two frames through the separate calls."""
+    import torch
+    import cpuvoxelraycaster_amd as vrc
+    nodes, svo = scene[7]
+    W, H, RB, N = 200, 100, 8, 3
+    light = vrc.reference_light(7)
+    cam = vrc.reference_camera(7, pitch=-0.5)
+    L = vrc.capi.load()
+    nbytes = L.vrc_shard_bytes(W, H, RB, N)
+
+    def make():
+        rc = vrc.RayCaster(svo, (W, H))
+        rc.setLightPosition(light)
+        rc.use_gi = rc.use_samples = True
+        rc.shadow_samples = 1
+        return rc
+
+    for k in range(N):
+        a, b = make(), make()
+        sa = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+        sb = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+        for frame in range(2):
+            a.resetSamples()
+            a.renderFrame(cam, spp=2, row_block=RB, shard_index=k, shard_count=N)
+            a.samples_to_image()
+            a.packShard(RB, k, N, sa.data_ptr())
+            b.renderFrame(cam, spp=2, row_block=RB, shard_index=k, shard_count=N)
+            b.resolveShard(RB, k, N, sb.data_ptr(), reset=True)
+            torch.cuda.synchronize()
+            assert torch.equal(sa, sb)
+            assert np.array_equal(a.readImage(), b.readImage())
+            assert not b.readAccum().any()
+    # whole frame, no reset: accumulators stay, image equals samples_to_image
+    a, b = make(), make()
+    a.renderFrame(cam, spp=3)
+    b.renderFrame(cam, spp=3)
+    a.samples_to_image()
+    b.resolveShard()
+    assert np.array_equal(a.readImage(), b.readImage())
+    assert np.array_equal(a.readAccum(), b.readAccum()) and b.readAccum().any()
+    # reset only touches the shard's rows
+    b.resolveShard(RB, 1, N, None, reset=True)
+    acc = b.readAccum()
+    rows = np.arange(H)
+    mine = (rows // RB) % N == 1
+    assert not acc[mine].any() and np.array_equal(acc[~mine], a.readAccum()[~mine])
+
+
 def test_full_size_properties(scene, textures):
     """BASELINE config 3 size (512^3, 1920x1080, GI): size-independent checks."""
     import cpuvoxelraycaster_amd as vrc
