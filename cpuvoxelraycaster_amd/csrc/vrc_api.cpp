@@ -400,7 +400,7 @@ extern "C" int vrc_render_frame(vrc_renderer* r, const vrc_camera* cam, const vr
         uint32_t c = g_tuning.sample_chunk ? g_tuning.sample_chunk : a.p.spp;
         if (!g_tuning.sample_chunk) {
             while (c > 2 && tiles * ((a.p.spp + c - 1) / c) < 48 * waves) c = (c + 1) / 2;
-            if (c == 2 && tiles * ((a.p.spp + 1) / 2) < 12 * waves) c = 1;
+            if (c == 2 && tiles * ((a.p.spp + 1) / 2) < 8 * waves) c = 1;
         }
         a.sample_chunk = c < a.p.spp ? c : 0;
         // one wave per unit until the chip is full: a shard of few tiles still spreads over all CUs

@@ -1075,8 +1075,11 @@ k_render_sync(const FrameArgs a)
                 v.x += acc_r; v.y += acc_g; v.z += acc_b; v.w += spp;
                 *ap = v;
             } else {
-                uint32_t* ap = a.accum + 4ull * pix;
-                atomicAdd(ap + 0, acc_r); atomicAdd(ap + 1, acc_g); atomicAdd(ap + 2, acc_b); atomicAdd(ap + 3, s_end - s_begin);
+                // two 64-bit adds per pixel: (r, g) and (b, count) as pairs of u32 -- a sum never carries out of its
+                // low word (sums < 2^32, as the accumulator format requires), so each half adds independently
+                unsigned long long* ap = reinterpret_cast<unsigned long long*>(a.accum + 4ull * pix);
+                atomicAdd(ap + 0, (unsigned long long)acc_r | ((unsigned long long)acc_g << 32));
+                atomicAdd(ap + 1, (unsigned long long)acc_b | ((unsigned long long)(s_end - s_begin) << 32));
             }
         }
     }
