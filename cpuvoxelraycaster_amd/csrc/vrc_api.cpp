@@ -124,7 +124,7 @@ extern "C" int vrc_scene_create(const vrc_lnode* lnodes, uint64_t n_nodes, uint3
 {
     if (!lnodes || !out || n_nodes == 0) return fail(VRC_ERR_INVALID, "vrc_scene_create: null / empty input");
     if (depth < 2 || depth > VRC_MAX_DEPTH) return fail(VRC_ERR_INVALID, "vrc_scene_create: depth %u not in [2,%d]", depth, VRC_MAX_DEPTH);
-    if (n_nodes > 0xffffffffull) return fail(VRC_ERR_INVALID, "vrc_scene_create: node indices are 32-bit");
+    if (n_nodes > VRC_MAX_NODES) return fail(VRC_ERR_INVALID, "vrc_scene_create: more than 2^29 nodes (4 GiB) are not addressable by the walk");
     int cus = 0;
     int rc = require_device(device, &cus);
     if (rc) return rc;

@@ -169,7 +169,7 @@ int build_on_device(Vox vox, uint32_t depth, int device, int cus, vrc_scene** ou
     }
     HIP_TRYB(hipMemcpy(&root_cnt, cnt[0], 4, hipMemcpyDeviceToHost));
     n_nodes = 1ull + 8ull * root_cnt;                 // data = { root } + 8 slots per internal node
-    if (n_nodes > 0xffffffffull) { rc = vrc::fail(VRC_ERR_INVALID, "scene needs more than 2^32 nodes"); goto done; }
+    if (n_nodes > VRC_MAX_NODES) { rc = vrc::fail(VRC_ERR_INVALID, "scene needs more than 2^29 nodes (4 GiB)"); goto done; }
     HIP_TRYB(hipMalloc(&d_nodes, n_nodes * sizeof(vrc_lnode)));
     hipLaunchKernelGGL(k_fill_blank_nodes, grid_for(n_nodes), dim3(256), 0, nullptr, (uint2*)d_nodes, n_nodes);
     if (root_cnt == 0) {

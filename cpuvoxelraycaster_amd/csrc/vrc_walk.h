@@ -94,18 +94,21 @@ namespace vrc {
     "v_pk_add_f32 v[50:51], v[50:51], v[48:49]\n"                                               \
     "v_add_f32_e32 v53, v53, v52\n"                                                             \
     "v_min_f32_e32 v43, v43, %[tc]\n"           /* :110 t_max = tv_max */                       \
-    "v_cmp_gt_f32_e64 %[sa], v50, v41\n"        /* :107-109 */                                  \
-    "v_cmp_gt_f32_e64 %[sb], v51, v41\n"                                                        \
-    "v_cmp_gt_f32_e32 vcc, v53, v41\n"                                                          \
+    /* :107-109 without masks (anything touching VCC / an SGPR costs ~1.7x a plain VALU op): th > t_min is the \
+       sign of t_min - th (never -0: t_min >= +0; never NaN: both finite), and pos + half sets bit scale-1 of   \
+       the mantissa, which is 0 before (pos is a multiple of 2 * half in [1, 2)) */                          \
+    "v_sub_f32_e32 v50, v41, v50\n"                                                             \
+    "v_sub_f32_e32 v51, v41, v51\n"                                                             \
+    "v_sub_f32_e32 v53, v41, v53\n"                                                             \
     "v_add_u32_e32 %[scale], -1, %[scale]\n"    /* :104 */                                      \
-    "v_cndmask_b32_e64 %[co], 0, 1, vcc\n"      /* child = z*4 + y*2 + x: n = 2n + bit by add-with-carry */ \
-    "v_cndmask_b32_e64 v50, 0, v44, %[sa]\n"                                                    \
-    "v_addc_co_u32_e64 %[co], %[st], %[co], %[co], %[sb]\n"                                     \
-    "v_cndmask_b32_e64 v51, 0, v44, %[sb]\n"                                                    \
-    "v_cndmask_b32_e32 v53, 0, v44, vcc\n"                                                      \
-    "v_addc_co_u32_e64 %[co], %[st], %[co], %[co], %[sa]\n"                                     \
-    "v_pk_add_f32 v[38:39], v[38:39], v[50:51]\n"                                               \
-    "v_add_f32_e32 v40, v40, v53\n"                                                             \
+    "v_lshrrev_b32_e32 v50, 31, v50\n"                                                          \
+    "v_lshrrev_b32_e32 v51, 31, v51\n"                                                          \
+    "v_lshrrev_b32_e32 v53, 31, v53\n"                                                          \
+    "v_lshl_or_b32 v38, v50, %[scale], v38\n"                                                   \
+    "v_lshl_or_b32 v39, v51, %[scale], v39\n"                                                   \
+    "v_lshl_or_b32 v40, v53, %[scale], v40\n"                                                   \
+    "v_lshl_or_b32 %[co], v51, 1, v50\n"                                                        \
+    "v_lshl_or_b32 %[co], v53, 2, %[co]\n"                                                      \
     /* ---- advance :113-122 ---- */                                                            \
     "Lwalk_adv%=:\n"                                                                            \
     "s_andn2_b64 exec, %[srun], %[sin]\n"                                                       \

@@ -38,6 +38,7 @@ extern "C" {
 #define VRC_MEM_DEVICE 1
 
 #define VRC_MAX_DEPTH 11          /* the loop bound of lsvo.hpp:72 binds from depth 12 on */
+#define VRC_MAX_NODES (1ull << 29) /* 4 GiB of LNodes: the walk addresses a node by a 32-bit byte offset */
 
 /* include/lsvo_utils.hpp:5-18 -- the 8-byte linear octree node the kernels
  * consume: index 0 = root; a non-empty internal node i owns the 8 consecutive
