@@ -47,6 +47,18 @@ __global__ void k(float* out, int iters, unsigned long long* cyc)
             REP16(asm volatile("v_xor_b32_e32 %0, %0, %2\n v_lshrrev_b32_e32 %1, %2, %1" : "+v"(e), "+v"(f) : "v"(b.x));)
         } else if (MODE == 15) { // v_mov
             REP16(asm volatile("v_mov_b32_e32 %0, %2\n v_mov_b32_e32 %1, %3" : "+v"(e), "+v"(f) : "v"(b.x), "v"(b.y));)
+        } else if (MODE == 17) { // plain adds with only the low 32 lanes enabled: does a SIMD-32 skip the empty half?
+            asm volatile("s_mov_b64 s[20:21], exec\n s_mov_b32 exec_hi, 0" : : : "s20", "s21");
+            REP16(asm volatile("v_add_f32 %0, %0, %2\n v_add_f32 %1, %1, %3" : "+v"(e), "+v"(f) : "v"(b.x), "v"(b.y));)
+            asm volatile("s_mov_b64 exec, s[20:21]" : : : "s20", "s21");
+        } else if (MODE == 18) { // ... with every other lane enabled
+            asm volatile("s_mov_b64 s[20:21], exec\n s_mov_b32 exec_lo, 0x55555555\n s_mov_b32 exec_hi, 0x55555555" : : : "s20", "s21");
+            REP16(asm volatile("v_add_f32 %0, %0, %2\n v_add_f32 %1, %1, %3" : "+v"(e), "+v"(f) : "v"(b.x), "v"(b.y));)
+            asm volatile("s_mov_b64 exec, s[20:21]" : : : "s20", "s21");
+        } else if (MODE == 19) { // 3-source op with only the low 32 lanes
+            asm volatile("s_mov_b64 s[20:21], exec\n s_mov_b32 exec_hi, 0" : : : "s20", "s21");
+            REP16(asm volatile("v_min3_f32 %0, %0, %2, %3\n v_min3_f32 %1, %1, %2, %3" : "+v"(e), "+v"(f) : "v"(b.x), "v"(b.y));)
+            asm volatile("s_mov_b64 exec, s[20:21]" : : : "s20", "s21");
         } else if (MODE == 8) { // 32 v_addc_co_u32
             REP16(asm volatile("v_addc_co_u32_e64 %0, s[20:21], %0, %0, vcc\n v_addc_co_u32_e64 %1, s[20:21], %1, %1, vcc" : "+v"(e), "+v"(f) : : "vcc", "s20", "s21");)
         }
@@ -99,5 +111,8 @@ int main()
     run<13>("cmp/cndmask/addc e64 x48", 48);
     run<14>("v_xor / v_lshrrev e32 x32", 32);
     run<15>("v_mov_b32 x32", 32);
+    run<17>("v_add_f32 x32, low 32 lanes", 32);
+    run<18>("v_add_f32 x32, even lanes", 32);
+    run<19>("v_min3_f32 x32, low 32 lanes", 32);
     return 0;
 }
