@@ -21,6 +21,20 @@
 
 namespace vrc {
 
+// The span test of :81 / :89, t_min <= min(t_max, tc) (no NaN in the walk).  Without a LOD test one min and one
+// compare (a compare costs 1.7x a min); with it `t_min <= t_max` is needed on its own (:81 guards :82), so two compares.
+#define VRC_WALK_SPAN_MIN                                                                       \
+    "v_min_f32_e32 %[t2], v43, %[tc]\n"         /* :86 tv_max */                                \
+    "v_cmp_le_f32_e32 vcc, v41, %[t2]\n"                                                        \
+    "s_and_b64 %[sin], %[schild], vcc\n"
+#define VRC_WALK_TMAX_MIN "v_mov_b32_e32 v43, %[t2]\n"
+#define VRC_WALK_SPAN_CMP                                                                       \
+    "v_cmp_le_f32_e32 vcc, v41, v43\n"          /* :81 t_min <= t_max */                        \
+    "s_and_b64 %[stm], %[schild], vcc\n"                                                        \
+    "v_cmp_le_f32_e32 vcc, v41, %[tc]\n"        /* with the line above: t_min <= min(t_max, tc), :86,:89 */ \
+    "s_and_b64 %[sin], %[stm], vcc\n"
+#define VRC_WALK_TMAX_CMP "v_min_f32_e32 v43, v43, %[tc]\n"
+
 // LOD_MODE: 0 = no LOD test (coef == bias == 0), 1 = bias == 0 (x + 0 does not change the comparison),
 // 2 = general.
 #define VRC_WALK_LOD_NONE ""
@@ -43,7 +57,7 @@ namespace vrc {
 // v32:33 t_coef.xy  v34 t_coef.z  v35 t_offset.z  v36:37 t_offset.xy  v38:39 pos.xy  v40 pos.z
 // v41 t_min  v42:43 {parent_id, t_max} (the stack entry)  v44 scale_f (v45 h)  v46:47 node
 // v48:49 c.xy  v52 c.z  v50:51 / v53 per-axis step / half-point scratch
-#define VRC_WALK_ASM(LODPART)                                                                   \
+#define VRC_WALK_ASM(SPANPART, LODPART, TMAXPART)                                                                   \
     "s_mov_b64 %[sentry], exec\n"                                                               \
     "s_mov_b64 %[sleaf], 0\n"                                                                   \
     "s_mov_b64 %[slod], 0\n"                                                                    \
@@ -64,10 +78,7 @@ namespace vrc {
     "v_and_b32_e32 %[t], 0x10100, %[m]\n"       /* leaf_mask is a subset of child_mask (k_sanitize_nodes): 0, 0x100 or 0x10100 */ \
     "v_min3_f32 %[tc], v48, v49, v52\n"         /* :77 */                                       \
     "v_cmp_ne_u32_e64 %[schild], 0, %[t]\n"                                                     \
-    "v_cmp_le_f32_e32 vcc, v41, v43\n"          /* :81 t_min <= t_max */                        \
-    "s_and_b64 %[stm], %[schild], vcc\n"                                                        \
-    "v_cmp_le_f32_e32 vcc, v41, %[tc]\n"        /* with the line above: t_min <= min(t_max, tc), :86,:89 */ \
-    "s_and_b64 %[sin], %[stm], vcc\n"                                                           \
+    SPANPART                                                                                    \
     LODPART                                                                                     \
     "v_cmp_lt_u32_e32 vcc, 0x100, %[t]\n"       /* child and leaf */                            \
     "s_and_b64 %[st], %[sin], vcc\n"            /* leaf hit :90-94 */                           \
@@ -93,7 +104,7 @@ namespace vrc {
     "v_mul_f32_e32 v53, v34, v44\n"                                                             \
     "v_pk_add_f32 v[50:51], v[50:51], v[48:49]\n"                                               \
     "v_add_f32_e32 v53, v53, v52\n"                                                             \
-    "v_min_f32_e32 v43, v43, %[tc]\n"           /* :110 t_max = tv_max */                       \
+    TMAXPART                                    /* :110 t_max = tv_max */                       \
     /* :107-109 without masks (anything touching VCC / an SGPR costs ~1.7x a plain VALU op): th > t_min is the \
        sign of t_min - th (never -0: t_min >= +0; never NaN: both finite), and pos + half sets bit scale-1 of   \
        the mantissa, which is 0 before (pos is a multiple of 2 * half in [1, 2)) */                          \
@@ -197,9 +208,9 @@ __device__ __forceinline__ void ray_walk(Ray& r, bool active, const uint2* __res
         : "{v32}"(tcx), "{v33}"(tcy), "{v34}"(tcz), "{v35}"(toz), "{v36}"(tox), "{v37}"(toy),                         \
           [mirror] "v"(r.mirror), [stkb] "v"(stkb), [nodes] "s"(nodes), [sfc] "s"(sfc), [coef] "v"(coef), [bias] "v"(bias) \
         : "v48", "v49", "v50", "v51", "v52", "v53", "vcc", "scc", "memory"
-    if (LOD_MODE == 0) asm volatile(VRC_WALK_ASM(VRC_WALK_LOD_NONE) VRC_WALK_OPERANDS);
-    else if (LOD_MODE == 1) asm volatile(VRC_WALK_ASM(VRC_WALK_LOD_COEF) VRC_WALK_OPERANDS);
-    else asm volatile(VRC_WALK_ASM(VRC_WALK_LOD_FULL) VRC_WALK_OPERANDS);
+    if (LOD_MODE == 0) asm volatile(VRC_WALK_ASM(VRC_WALK_SPAN_MIN, VRC_WALK_LOD_NONE, VRC_WALK_TMAX_MIN) VRC_WALK_OPERANDS);
+    else if (LOD_MODE == 1) asm volatile(VRC_WALK_ASM(VRC_WALK_SPAN_CMP, VRC_WALK_LOD_COEF, VRC_WALK_TMAX_CMP) VRC_WALK_OPERANDS);
+    else asm volatile(VRC_WALK_ASM(VRC_WALK_SPAN_CMP, VRC_WALK_LOD_FULL, VRC_WALK_TMAX_CMP) VRC_WALK_OPERANDS);
 #undef VRC_WALK_OPERANDS
     r.px = px; r.py = py; r.pz = pz; r.t_min = t_min; r.t_max = t_max; r.scale_f = sf; r.h = h;
     r.parent_id = pid; r.nd = make_uint2(ndx, ndy);
