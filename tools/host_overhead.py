@@ -1,6 +1,9 @@
 """Fixed per-frame cost of the multi-GPU step on a tiny frame (64x32): host enqueue time and GPU launch latencies."""
-import sys, time
-sys.path.insert(0, '/root/repo')
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import cpuvoxelraycaster_amd as vrc
 depth = 7
