@@ -112,7 +112,13 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
-    if not os.path.exists(vrc.capi.LIB_PATH):
+    # the in-tree libraries travel with the snapshot; if they are missing or stale, ONE process per node builds
+    # (N ranks writing the same .so at once would corrupt it) and the others wait
+    if world > 1:
+        if local_rank == 0:
+            g.build()
+        dist.barrier()
+    else:
         g.build()
     if args.tuning:
         vrc.capi.check(vrc.capi.load().vrc_set_tuning(*[int(v) for v in args.tuning.split(",")]))
