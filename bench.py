@@ -31,6 +31,9 @@ CONFIGS = {
     "c3": dict(depth=9, width=1920, height=1080, spp=4, use_gi=1, aperture=0.0,
                label="512^3 LSVO terrain (FastNoise seed 1337, generated and built on the GPU), 1920x1080, 4 spp GI "
                      "(1 indirect bounce), shadow_samples=1"),
+    "c3b2": dict(depth=9, width=1920, height=1080, spp=4, use_gi=1, aperture=0.0, gi_bounces=2,
+                 label="512^3 LSVO terrain, 1920x1080, 4 spp GI with the 2-bounce EXTENSION (recursive S2 at the GI hit; the "
+                       "reference never reads gi_bounce, SURVEY App. C), shadow_samples=1"),
     "c3nogi": dict(depth=9, width=1920, height=1080, spp=4, use_gi=0, aperture=0.0,
                    label="512^3 LSVO terrain, 1920x1080, 4 spp, primary + 1 shadow ray (no GI)"),
     "c4": dict(depth=9, width=1920, height=1080, spp=4, use_gi=1, aperture=0.5,
@@ -61,7 +64,7 @@ def cpu_baseline(cfg, nodes, textures, cam, light, budget_s=12.0):
         # sample s of the frame, shard by shard (later passes repeat the workload with the next sample indices)
         for k in range(shards):
             p = O.make_params(W, H, light, use_gi=cfg["use_gi"], use_samples=1, shadow_samples=1, frame_index=s,
-                              row_block=ROW_BLOCK, shard_index=k, shard_count=shards)
+                              gi_bounces=cfg.get("gi_bounces", 1), row_block=ROW_BLOCK, shard_index=k, shard_count=shards)
             _, _, _, st = O.render_frame(nodes, cfg["depth"], top, side, ocam, p, threads=threads)
             rays += st.rays
             done += 1
@@ -134,6 +137,7 @@ def main():
     light = vrc.reference_light(depth)
     rc.setLightPosition(light)
     rc.use_gi, rc.use_samples, rc.shadow_samples = bool(cfg["use_gi"]), True, 1
+    rc.gi_bounces = cfg.get("gi_bounces", 1)
     cam = vrc.reference_camera(depth, pitch=args.pitch, aperture=cfg["aperture"],
                                focal_length=(60.0 * (1 << depth) / 512.0 if cfg["aperture"] else 1.0))
     stream = torch.cuda.current_stream().cuda_stream
@@ -234,6 +238,7 @@ def main():
         ref = vrc.RayCaster(svo, (W, H))
         ref.setLightPosition(light)
         ref.use_gi, ref.use_samples, ref.shadow_samples = bool(cfg["use_gi"]), True, 1
+        ref.gi_bounces = cfg.get("gi_bounces", 1)
         ref.frame_index = rc.frame_index - spp
         ref.renderFrame(cam, spp=spp, stream=stream)
         ref.samples_to_image(stream)
