@@ -43,6 +43,7 @@ struct Tuning {
     uint32_t kernel = VRC_KERNEL_SYNC;
     bool blocks_per_cu_set = false;
     uint32_t sample_chunk = 0;   // 0 = automatic
+    uint32_t tail_units_per_wave = 5;   // automatic chunking: units of half the chunk for the last tiles (0 = off)
 } g_tuning;
 
 }  // namespace
@@ -95,6 +96,8 @@ using vrc::require_device;
 
 extern "C" int vrc_set_sample_chunk(uint32_t samples_per_unit)
 {
+    // values above 0xffff0000 set the tail policy of the automatic mode instead (experiments): low 16 bits = units per wave
+    if (samples_per_unit >= 0xffff0000u) { g_tuning.tail_units_per_wave = samples_per_unit & 0xffffu; return VRC_OK; }
     g_tuning.sample_chunk = samples_per_unit;
     return VRC_OK;
 }
@@ -403,8 +406,17 @@ extern "C" int vrc_render_frame(vrc_renderer* r, const vrc_camera* cam, const vr
             if (c == 2 && tiles * ((a.p.spp + 1) / 2) < 8 * waves) c = 1;
         }
         a.sample_chunk = c < a.p.spp ? c : 0;
+        // shorter units for the tiles handed out last (about five per wave): halves the spread of the waves' end times
+        uint64_t units = tiles * ((a.p.spp + c - 1) / c);
+        if (!g_tuning.sample_chunk && c >= 2 && g_tuning.tail_units_per_wave) {
+            const uint32_t ct = c / 2, cpt_tail = (a.p.spp + ct - 1) / ct;
+            uint64_t tt = (uint64_t)g_tuning.tail_units_per_wave * waves / cpt_tail;
+            if (tt > tiles) tt = tiles;
+            a.sample_chunk_tail = ct;
+            a.tail_tiles = (uint32_t)tt;
+            units = (tiles - tt) * ((a.p.spp + c - 1) / c) + tt * cpt_tail;
+        }
         // one wave per unit until the chip is full: a shard of few tiles still spreads over all CUs
-        const uint64_t units = tiles * ((a.p.spp + c - 1) / c);
         want = (units + VRC_RENDER_BLOCK / 64 - 1) / (VRC_RENDER_BLOCK / 64);
     }
     const uint32_t grid = (uint32_t)(want < cap ? want : cap);

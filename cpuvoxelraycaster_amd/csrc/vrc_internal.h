@@ -49,6 +49,7 @@ struct FrameArgs {
     uint32_t chunk;           // items a wave takes from the queue at once
     uint32_t refill_threshold;// leave the traversal loop once this many lanes wait
     uint32_t sample_chunk;    // k_render_sync: samples per work unit (0 = all spp in one unit)
+    uint32_t sample_chunk_tail, tail_tiles;   // ... and for the last `tail_tiles` tiles (0 = same chunk)
     vrc_camera cam;
     vrc_frame_params p;
 };

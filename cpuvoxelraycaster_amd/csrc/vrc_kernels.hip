@@ -867,9 +867,15 @@ k_render_sync(const FrameArgs a)
     // Work unit = (tile, chunk of `sample_chunk` samples).  With few tiles per GPU (multi-GPU shards)
     // the host splits a pixel's samples over several units so every wave still gets several units;
     // the accumulators are then updated with integer atomics (exact, order-independent).
-    const uint32_t chunk = a.sample_chunk ? a.sample_chunk : spp;
-    const uint32_t chunks_per_tile = (spp + chunk - 1u) / chunk;
-    const uint32_t n_units = n_tiles * chunks_per_tile;
+    // The last `tail_tiles` tiles may use a smaller chunk (`sample_chunk_tail`): units get shorter towards the end of
+    // the launch, when what matters is how long the last ones take.
+    const uint32_t chunk_head = a.sample_chunk ? a.sample_chunk : spp;
+    const uint32_t cpt_head = (spp + chunk_head - 1u) / chunk_head;
+    const uint32_t chunk_tail = a.sample_chunk_tail ? a.sample_chunk_tail : chunk_head;
+    const uint32_t cpt_tail = (spp + chunk_tail - 1u) / chunk_tail;
+    const uint32_t tail_tiles = min(a.tail_tiles, n_tiles), head_tiles = n_tiles - tail_tiles;
+    const uint32_t head_units = head_tiles * cpt_head;
+    const uint32_t n_units = head_units + tail_tiles * cpt_tail;
 
     uint32_t n_rays = 0u, n_steps = 0u, n_hits = 0u, n_pix = 0u;
 
@@ -918,12 +924,11 @@ k_render_sync(const FrameArgs a)
             probe_last_unit = unit;
         }
 #endif
-#ifdef VRC_REVERSE
-        const uint32_t tile = n_tiles - 1u - unit / chunks_per_tile;
-#else
-        const uint32_t tile = unit / chunks_per_tile;
-#endif
-        const uint32_t s_begin = (unit % chunks_per_tile) * chunk, s_end = min(spp, s_begin + chunk);
+        const bool in_tail = unit >= head_units;
+        const uint32_t chunks_per_tile = in_tail ? cpt_tail : cpt_head, chunk = in_tail ? chunk_tail : chunk_head;
+        const uint32_t u = in_tail ? unit - head_units : unit;
+        const uint32_t tile = (in_tail ? head_tiles : 0u) + u / chunks_per_tile;
+        const uint32_t s_begin = (u % chunks_per_tile) * chunk, s_end = min(spp, s_begin + chunk);
         const uint32_t tx = tile % tiles_per_row, ty = tile / tiles_per_row;
         const uint32_t px_x = tx * 8u + (lane & 7u);
         uint32_t px_y = ty * 8u + (lane >> 3);

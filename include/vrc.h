@@ -235,9 +235,11 @@ int vrc_set_tuning(uint32_t blocks_per_cu, uint32_t refill_threshold, uint32_t c
  * global work queue.  Results are bit-identical; 0 and 1 are kept for A/B. */
 int vrc_set_kernel(uint32_t kernel);
 /* Stage-synchronous kernel, sample mode: samples per work unit (tile x sample chunk).  0 =
- * automatic: all spp in one unit unless the frame (or this GPU's shard) has too few tiles
- * to give every wave several units; then a pixel's samples are split over units and
- * accumulated with integer atomics (same sums). */
+ * automatic: the largest chunk that still gives every wave a few dozen units (down to 1 sample
+ * per unit for small multi-GPU shards), and half that chunk for the tiles handed out last, so
+ * that units get shorter towards the end of a launch; a pixel's samples split over several
+ * units are accumulated with integer atomics (same sums).  Values >= 0xffff0000 set the
+ * automatic mode's tail policy instead: low 16 bits = units per wave with the halved chunk. */
 int vrc_set_sample_chunk(uint32_t samples_per_unit);
 
 #ifdef __cplusplus

@@ -13,6 +13,7 @@ def main():
     ap.add_argument("--config", default="c3")
     ap.add_argument("--chunks", default="0,1,2")
     ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--tails", default="", help="with --chunks 0: units per wave that get half the chunk at the end of the launch")
     args = ap.parse_args()
     import torch
     import bench
@@ -27,10 +28,16 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     L = vrc.capi.load()
     chunks = [int(c) for c in args.chunks.split(",")]
+    if args.tails:
+        chunks = [("tail", int(t)) for t in args.tails.split(",")]
     times = {c: [] for c in chunks}
     for r in range(args.rounds + 1):
         for c in chunks:
-            vrc.capi.check(L.vrc_set_sample_chunk(c))
+            if isinstance(c, tuple):
+                vrc.capi.check(L.vrc_set_sample_chunk(0))
+                vrc.capi.check(L.vrc_set_sample_chunk(0xffff0000 | c[1]))
+            else:
+                vrc.capi.check(L.vrc_set_sample_chunk(c))
             for f in range(3):
                 rc.resetSamples(stream)
                 rc.frame_index = 0
