@@ -864,6 +864,11 @@ k_render_sync(const FrameArgs a)
     const uint32_t tiles_per_row = (W + 7u) / 8u;
     const uint32_t n_tiles = a.n_items >> 6;
     const bool sharded = a.p.row_block && a.p.shard_count > 1u;
+    // Pinhole camera (aperture exactly +0, the reference's default): rand_vec = 0 * getRand() is +-0, which changes
+    // neither focal_point - rand_vec (focal_point.x / .y are never -0 when focal_length >= 1e-30: lens.x / .y are +0
+    // or non-zero, camera_controller.hpp:36-42) nor, after the `+ 1`, the origin -- so the two lens draws and the
+    // products with them are skipped.  Any other aperture or focal_length takes the general path.
+    const bool pinhole = f2u(a.cam.aperture) == 0u && a.cam.focal_length >= 1e-30f && a.cam.focal_length < __builtin_inff();
     // Work unit = (tile, chunk of `sample_chunk` samples).  With few tiles per GPU (multi-GPU shards)
     // the host splits a pixel's samples over several units so every wave still gets several units;
     // the accumulators are then updated with integer atomics (exact, order-independent).
@@ -951,18 +956,22 @@ k_render_sync(const FrameArgs a)
                 float sx = lens_x, sy = lens_y, sz = a.cam.fov;
                 normalize3(sx, sy, sz);
                 const float fx = sx * a.cam.focal_length, fy = sy * a.cam.focal_length, fz = sz * a.cam.focal_length;
-                const float r0 = get_rand(counter_rand(a.p.seed, fr, pix, 0u), -0.5f, 0.5f);
-                const float r1 = get_rand(counter_rand(a.p.seed, fr, pix, 1u), -0.5f, 0.5f);
-                const float rvx = a.cam.aperture * r0, rvy = a.cam.aperture * r1, rvz = a.cam.aperture * 0.0f;
-                float vx = fx - rvx, vy = fy - rvy, vz = fz - rvz;
-                normalize3(vx, vy, vz);
+                float vx = fx, vy = fy, vz = fz;
+                float wx = 0.0f, wy = 0.0f, wz = 0.0f;
                 const float* m = a.cam.rot;
+                if (!pinhole) {
+                    const float r0 = get_rand(counter_rand(a.p.seed, fr, pix, 0u), -0.5f, 0.5f);
+                    const float r1 = get_rand(counter_rand(a.p.seed, fr, pix, 1u), -0.5f, 0.5f);
+                    const float rvx = a.cam.aperture * r0, rvy = a.cam.aperture * r1, rvz = a.cam.aperture * 0.0f;
+                    vx = fx - rvx; vy = fy - rvy; vz = fz - rvz;
+                    wx = (m[0] * rvx + m[1] * rvy) + m[2] * rvz;
+                    wy = (m[3] * rvx + m[4] * rvy) + m[5] * rvz;
+                    wz = (m[6] * rvx + m[7] * rvy) + m[8] * rvz;
+                }
+                normalize3(vx, vy, vz);
                 float dx = (m[0] * vx + m[1] * vy) + m[2] * vz;
                 float dy = (m[3] * vx + m[4] * vy) + m[5] * vz;
                 float dz = (m[6] * vx + m[7] * vy) + m[8] * vz;
-                const float wx = (m[0] * rvx + m[1] * rvy) + m[2] * rvz;
-                const float wy = (m[3] * rvx + m[4] * rvy) + m[5] * rvz;
-                const float wz = (m[6] * rvx + m[7] * rvy) + m[8] * rvz;
                 float ox = (a.cam.position[0] + wx) * inv_size + 1.0f;
                 float oy = (a.cam.position[1] + wy) * inv_size + 1.0f;
                 float oz = (a.cam.position[2] + wz) * inv_size + 1.0f;

@@ -109,6 +109,14 @@ def test_dof(scene, textures):
     run_pair(scene, textures, 9, 320, 180, -0.5, spp=2, use_gi=1, aperture=0.5, focal_length=60.0)
 
 
+@pytest.mark.parametrize("aperture,focal_length", [(0.0, 1.0), (0.0, 37.5), (0.0, -1.0), (-0.0, 1.0), (0.0, 1e-35), (1e-30, 1.0)])
+def test_pinhole_shortcut_is_exact(scene, textures, aperture, focal_length):
+    """aperture == +0 skips the two lens draws (rand_vec = 0 * getRand() is +-0): exact only while focal_point.x / .y
+    cannot be -0, so negative / tiny focal lengths and a -0 aperture must take the general path.  Even widths put
+    lens.x = +0 on the centre column (the case where the sign of a zero would show), primary hits are compared too."""
+    run_pair(scene, textures, 7, 160, 90, -0.5, spp=2, use_gi=1, aperture=aperture, focal_length=focal_length, capture=True)
+
+
 def test_temporal_blend_checkerboard(scene, textures):
     """Non-sample mode: 0.4/0.6 temporal blend (raycaster.hpp:77-85) over 4 checkerboard frames."""
     run_pair(scene, textures, 9, 320, 180, -0.5, frames=4, use_gi=1, use_samples=0, checker=True)
