@@ -81,3 +81,20 @@ def test_replay_reader_matches_reference_format(built, tmp_path):
     assert [float(v) for v in out[1:]] == [v for t in ticks for v in t]
     assert subprocess.run([exe, str(tmp_path / "missing")], capture_output=True, text=True).stdout == "0"
     assert replay_bench.load_replay(str(tmp_path / "missing")) == []
+
+
+def test_argument_validation_needs_no_gpu(built):
+    """Bad arguments are refused before any HIP call: depth range, more than VRC_MAX_NODES nodes (the walk addresses a
+    node by a 32-bit byte offset), null pointers, bad shard description."""
+    from cpuvoxelraycaster_amd import capi
+    L = capi.load()
+    nodes = np.zeros(8, capi.LNODE_DTYPE)
+    h = C.c_void_p()
+    assert L.vrc_scene_create(capi.ptr(nodes), (1 << 29) + 1, 9, 0, C.byref(h)) == -1
+    assert b"2^29" in L.vrc_last_error()
+    assert L.vrc_scene_create(capi.ptr(nodes), 8, 12, 0, C.byref(h)) == -1
+    assert L.vrc_scene_create(capi.ptr(nodes), 8, 1, 0, C.byref(h)) == -1
+    assert L.vrc_scene_create(None, 8, 9, 0, C.byref(h)) == -1
+    assert L.vrc_resolve_shard(None, 8, 0, 1, None, 0, None) == -1
+    assert L.vrc_unpack_shards(None, 16, 16, 8, 2, None, None) == -1
+    assert L.vrc_shard_bytes(1920, 1080, 8, 8) == 17 * 8 * 1920 * 4
