@@ -3,10 +3,15 @@ the statistics SURVEY.md App. B / section 6 measured by running it (node counts,
 first nodes, level histogram, per-pose hit counts, loop-iteration statistics,
 normal-axis split, one sample hit).  The reference holds no tests or golden
 vectors of its own."""
+import os
+import sys
+
 import numpy as np
 import pytest
 
 import oracle_lib as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -221,3 +226,57 @@ def test_reference_probe_sequence_random_and_gi_rays(nodes9):
     assert (int((kind != 0).sum()), int((kind == 2).sum()), int((kind == 1).sum())) == (116671, 77971, 38700)
     hist = [int(((kind == 2) & (sc == s)).sum()) for s in range(14, 22)]
     assert hist == [12775, 13589, 14068, 16431, 14450, 3836, 2805, 17]
+
+
+def _host_replay_reader(tmp_path):
+    """The product's reader: vrc_host::ReplayElements::loadFromFile (host/hip_raycaster.hpp), as a tiny executable."""
+    import subprocess
+    hdr = os.path.join(ROOT, "cpuvoxelraycaster_amd", "host", "hip_raycaster.hpp")
+    src = ('#include "%s"\n#include <cstdio>\n#include <cstring>\nint main(int c, char** v){ auto l = vrc_host::ReplayElements::loadFromFile(v[1]);'
+           'std::printf("%%zu", l.size()); for (auto& e : l) { float f[6] = {e.timestamp, e.x, e.y, e.z, e.view_x, e.view_y};'
+           'for (float q : f) { unsigned u; std::memcpy(&u, &q, 4); std::printf(" %%u", u); } } return 0; }\n') % hdr
+    exe = str(tmp_path / "replay_reader")
+    subprocess.run(["g++", "-std=c++14", "-x", "c++", "-", "-o", exe, "-L" + os.path.join(ROOT, "cpuvoxelraycaster_amd"),
+                    "-l:libvrc_hip.so", "-Wl,-rpath," + os.path.join(ROOT, "cpuvoxelraycaster_amd")], input=src.encode(), check=True)
+
+    def read(path):
+        out = subprocess.run([exe, path], capture_output=True, text=True, check=True).stdout.split()
+        vals = [int(v) for v in out[1:]]
+        assert len(vals) == 6 * int(out[0])
+        return [vals[i:i + 6] for i in range(0, len(vals), 6)]
+    return read
+
+
+def test_replay_reader_pinned_by_reference_execution(built, tmp_path):
+    """N3: tests/golden/replay_cases.json holds what the reference's own ReplayElements::loadFromFile
+    (include/replay.hpp, compiled where it lies: oracle/_ref/libref_replay.so, tools/make_golden_replay.py) parses from
+    a set of replay texts -- ticks spanning lines, numbers glued to text, truncated and malformed ticks, float32
+    overflow, nan / hex words.  The host adapter's reader and the Python replay driver must return the same ticks bit
+    for bit; where /root/reference is mounted the live reference reader is checked against the fixture too."""
+    import ctypes as C
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import replay_bench
+    cases = json.load(open(os.path.join(ROOT, "tests", "golden", "replay_cases.json")))
+    assert len(cases) >= 10
+    read_host = _host_replay_reader(tmp_path)
+    ref = None
+    ref_lib = os.path.join(ROOT, "oracle", "_ref", "libref_replay.so")
+    if os.path.isdir("/root/reference") and os.path.exists(ref_lib):
+        ref = C.CDLL(ref_lib)
+        ref.ref_replay_load.restype = C.c_int32
+        ref.ref_replay_load.argtypes = [C.c_char_p, C.c_void_p, C.c_int32]
+    for name, case in cases.items():
+        path = str(tmp_path / (name + ".replay"))
+        with open(path, "w") as f:
+            f.write(case["text"])
+        want = case["ticks_f32_bits"]
+        assert read_host(path) == want, name
+        got_py = np.array(replay_bench.load_replay(path), np.float32).reshape(-1, 6).view(np.uint32).tolist()
+        assert got_py == want, name
+        if ref is not None:
+            buf = np.zeros((64, 6), np.float32)
+            n = ref.ref_replay_load(path.encode(), buf.ctypes.data, 64)
+            assert buf[:n].view(np.uint32).tolist() == want, name
+    missing = str(tmp_path / "does_not_exist.replay")
+    assert read_host(missing) == [] and replay_bench.load_replay(missing) == []

@@ -9,23 +9,63 @@ import math
 import os
 import sys
 
+import numpy as np
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def _extract_float(text, pos):
+    """One `file >> float` of the reference's reader (replay.hpp:24, libstdc++ num_get): skip whitespace, collect
+    [sign] digits [. digits] [e [sign] digits] as far as the characters fit, convert; returns (value, new_pos) or
+    (None, pos) when the extraction fails (nothing collected, incomplete exponent, float32 overflow)."""
+    n = len(text)
+    while pos < n and text[pos].isspace():
+        pos += 1
+    i = pos
+    if i < n and text[i] in "+-":
+        i += 1
+    digits = 0
+    while i < n and text[i].isdigit():
+        i += 1; digits += 1
+    if i < n and text[i] == ".":
+        i += 1
+        while i < n and text[i].isdigit():
+            i += 1; digits += 1
+    if digits and i < n and text[i] in "eE":
+        i += 1
+        if i < n and text[i] in "+-":
+            i += 1
+        while i < n and text[i].isdigit():
+            i += 1
+    try:
+        v = float(text[pos:i])
+    except ValueError:
+        return None, pos
+    v32 = float(np.float32(v)) if abs(v) < 3.5e38 else math.inf
+    if math.isinf(v32):
+        return None, pos
+    return v32, i
+
+
 def load_replay(path):
-    """Same semantics as ReplayElements::loadFromFile: stop at the first malformed tick."""
+    """Same ticks as ReplayElements::loadFromFile (include/replay.hpp:18-33): values are read one `>>` at a time, so a
+    tick may span lines and a number may be glued to following text; reading stops at the first failed extraction;
+    a missing file gives no ticks.  Pinned against the reference's reader by tests/golden/replay_cases.json."""
     ticks = []
     try:
-        tokens = open(path).read().split()
+        text = open(path).read()
     except OSError:
         return ticks
-    for i in range(0, len(tokens) - 5, 6):
-        try:
-            ticks.append(tuple(float(v) for v in tokens[i:i + 6]))
-        except ValueError:
-            break
-    return ticks
+    pos = 0
+    while True:
+        vals = []
+        for _ in range(6):
+            v, pos = _extract_float(text, pos)
+            if v is None:
+                return ticks
+            vals.append(v)
+        ticks.append(tuple(vals))
 
 
 def synthetic_orbit(path, n=60, size=512.0):
