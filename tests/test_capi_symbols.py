@@ -78,7 +78,7 @@ def test_replay_reader_matches_reference_format(built, tmp_path):
     out = subprocess.run([exe, str(good)], capture_output=True, text=True).stdout.split()
     ticks = replay_bench.load_replay(str(good))
     assert int(out[0]) == len(ticks) == 2
-    assert [float(v) for v in out[1:]] == [v for t in ticks for v in t]
+    assert [np.float32(v) for v in out[1:]] == [np.float32(v) for t in ticks for v in t]
     assert subprocess.run([exe, str(tmp_path / "missing")], capture_output=True, text=True).stdout == "0"
     assert replay_bench.load_replay(str(tmp_path / "missing")) == []
 
