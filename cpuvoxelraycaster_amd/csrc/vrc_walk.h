@@ -124,16 +124,16 @@ namespace vrc {
     "Lwalk_adv%=:\n"                                                                            \
     "s_andn2_b64 exec, %[srun], %[sin]\n"                                                       \
     "s_cbranch_execz Lwalk_next%=\n"                                                            \
-    "v_cmp_le_f32_e64 %[sa], v48, %[tc]\n"      /* :115-118 */                                  \
-    "v_cmp_le_f32_e64 %[sb], v49, %[tc]\n"                                                      \
+    "v_cmp_le_f32_e64 %[schild], v48, %[tc]\n"      /* :115-118 */                                  \
+    "v_cmp_le_f32_e64 %[stm], v49, %[tc]\n"                                                      \
     "v_cmp_le_f32_e32 vcc, v52, %[tc]\n"                                                        \
     "v_mov_b32_e32 v41, %[tc]\n"                /* :120 */                                      \
     "v_cndmask_b32_e64 %[normal], 0, 1, vcc\n"                                                  \
-    "v_cndmask_b32_e64 v50, 0, v44, %[sa]\n"                                                    \
-    "v_addc_co_u32_e64 %[normal], %[st], %[normal], %[normal], %[sb]\n"                         \
-    "v_cndmask_b32_e64 v51, 0, v44, %[sb]\n"                                                    \
+    "v_cndmask_b32_e64 v50, 0, v44, %[schild]\n"                                                    \
+    "v_addc_co_u32_e64 %[normal], %[st], %[normal], %[normal], %[stm]\n"                         \
+    "v_cndmask_b32_e64 v51, 0, v44, %[stm]\n"                                                    \
     "v_cndmask_b32_e32 v53, 0, v44, vcc\n"                                                      \
-    "v_addc_co_u32_e64 %[normal], %[st], %[normal], %[normal], %[sa]\n"   /* :122 */            \
+    "v_addc_co_u32_e64 %[normal], %[st], %[normal], %[normal], %[schild]\n"   /* :122 */            \
     "v_pk_add_f32 v[38:39], v[38:39], v[50:51] neg_lo:[0,1] neg_hi:[0,1]\n"                     \
     "v_sub_f32_e32 v40, v40, v53\n"                                                             \
     "v_xor_b32_e32 %[co], %[co], %[normal]\n"   /* :121 */                                      \
@@ -191,7 +191,7 @@ __device__ __forceinline__ void ray_walk(Ray& r, bool active, const uint2* __res
     const uint32_t stkb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint2*)stk
                           - (uint32_t)(SVO_MAX - depth + 1) * 2048u;
     const uint32_t sfc = 104u << 23;            // (scale - 23 + 127) << 23 = (scale << 23) + (104 << 23)
-    uint64_t sentry, sleaf, slod, srun, sin_, schild, stm, st, sa, sb;
+    uint64_t sentry, sleaf, slod, srun, sin_, schild, stm, st;   // schild / stm double as the x / y step masks of the advance
     uint32_t siter, cs, m, t, t2, kind = 0u;
     float tc;
     float tcx = r.tcx, tcy = r.tcy, tcz = r.tcz, tox = r.tox, toy = r.toy, toz = r.toz;
@@ -203,7 +203,7 @@ __device__ __forceinline__ void ray_walk(Ray& r, bool active, const uint2* __res
           "+{v38}"(px), "+{v39}"(py), "+{v40}"(pz), "+{v41}"(t_min), "+{v42}"(pid), "+{v43}"(t_max),                  \
           "+{v44}"(sf), "+{v45}"(h), "+{v46}"(ndx), "+{v47}"(ndy),                                                    \
           [sentry] "=&s"(sentry), [sleaf] "=&s"(sleaf), [slod] "=&s"(slod), [srun] "=&s"(srun), [sin] "=&s"(sin_),    \
-          [schild] "=&s"(schild), [stm] "=&s"(stm), [st] "=&s"(st), [sa] "=&s"(sa), [sb] "=&s"(sb),                   \
+          [schild] "=&s"(schild), [stm] "=&s"(stm), [st] "=&s"(st),                                                   \
           [siter] "=&s"(siter), [cs] "=&v"(cs), [m] "=&v"(m), [t] "=&v"(t), [t2] "=&v"(t2), [tc] "=&v"(tc)            \
         : "{v32}"(tcx), "{v33}"(tcy), "{v34}"(tcz), "{v35}"(toz), "{v36}"(tox), "{v37}"(toy),                         \
           [mirror] "v"(r.mirror), [stkb] "v"(stkb), [nodes] "s"(nodes), [sfc] "s"(sfc), [coef] "v"(coef), [bias] "v"(bias) \
