@@ -142,9 +142,16 @@ public:
 
     // One frame: Camera::getRay + renderRay for every selected pixel (main.cpp:139-152).
     // checker_board_offset = -1 renders every pixel; 0 / 1 as main.cpp:137,143.
+    // Multi-GPU: this process renders the row blocks b (of `row_block` rows) with b % shard_count == shard_index.
+    void setShard(uint32_t row_block, uint32_t shard_index, uint32_t shard_count)
+    {
+        row_block_ = row_block; shard_index_ = shard_index; shard_count_ = shard_count ? shard_count : 1;
+    }
+
     void renderFrame(const CameraState& camera, int32_t checker_board_offset = -1, uint32_t spp = 1, void* stream = nullptr)
     {
         vrc_frame_params p{};
+        p.row_block = row_block_; p.shard_index = shard_index_; p.shard_count = shard_count_;
         p.light_position[0] = light_.x; p.light_position[1] = light_.y; p.light_position[2] = light_.z;
         p.use_gi = use_gi; p.use_samples = use_samples;
         p.shadow_samples = 0; p.gi_bounces = 1;
@@ -157,6 +164,12 @@ public:
 
     void samples_to_image(void* stream = nullptr) { check(vrc_samples_to_image(r_, stream), "vrc_samples_to_image"); }   // raycaster.hpp:94
     void resetSamples(void* stream = nullptr) { check(vrc_reset_samples(r_, stream), "vrc_reset_samples"); }            // raycaster.hpp:105
+    // samples_to_image for this shard's rows, written into `shard_dev` (device, vrc_shard_bytes) as the all-gather
+    // expects it; `reset` also clears those rows' accumulators (= resetSamples) in the same pass
+    void resolveShard(void* shard_dev, bool reset, void* stream = nullptr)
+    {
+        check(vrc_resolve_shard(r_, row_block_, shard_index_, shard_count_, shard_dev, reset ? 1 : 0, stream), "vrc_resolve_shard");
+    }
 
     // render_image (raycaster.hpp:261) copied to host RGBA8, row-major
     std::vector<uint8_t> render_image() const
@@ -181,6 +194,7 @@ private:
     vrc_renderer* r_ = nullptr;
     uint32_t width_, height_;
     uint32_t frame_index_ = 0;
+    uint32_t row_block_ = 0, shard_index_ = 0, shard_count_ = 1;
     Vec3 light_{0, 0, 0};
 };
 

@@ -8,6 +8,8 @@
 #include <fstream>
 #include <vector>
 
+#include <hip/hip_runtime_api.h>
+
 #include "../../cpuvoxelraycaster_amd/host/hip_raycaster.hpp"
 
 static std::vector<char> slurp(const char* path)
@@ -49,6 +51,26 @@ int main(int argc, char** argv)
         const vrc_frame_stats st = rc.stats();
         std::printf("frame sum=%llu fnv=%016llx rays=%llu steps=%llu\n", sum, fnv, (unsigned long long)st.rays,
                     (unsigned long long)st.sum_complexity);
+        // the same frame as three row-block shards (what three ranks would render), composed as an all-gather would
+        {
+            const uint32_t RB = 8, N = 3;
+            const uint64_t nbytes = vrc_shard_bytes(W, H, RB, N);
+            void *gathered = nullptr, *full = nullptr;
+            if (hipMalloc(&gathered, nbytes * N) != hipSuccess || hipMalloc(&full, (size_t)W * H * 4) != hipSuccess) return 3;
+            for (uint32_t k = 0; k < N; ++k) {
+                vrc_host::HipRayCaster part(lsvo, W, H);
+                part.setLightPosition({-200.0f / 512.0f + 1.0f, -1000.0f / 512.0f + 1.0f, -300.0f / 512.0f + 1.0f});
+                part.use_gi = true; part.use_samples = true;
+                part.setShard(RB, k, N);
+                part.renderFrame(cam, -1, 2);
+                part.resolveShard((char*)gathered + nbytes * k, true);
+            }
+            vrc_host::check(vrc_unpack_shards(gathered, W, H, RB, N, full, nullptr), "vrc_unpack_shards");
+            std::vector<uint8_t> composed((size_t)W * H * 4);
+            if (hipMemcpy(composed.data(), full, composed.size(), hipMemcpyDeviceToHost) != hipSuccess) return 3;
+            std::printf("sharded equal=%d\n", composed == img ? 1 : 0);
+            (void)hipFree(gathered); (void)hipFree(full);
+        }
     } catch (const std::exception& e) {
         std::printf("error %s\n", e.what());
         return 1;

@@ -24,14 +24,17 @@ def test_cpp_host_adapter_matches_oracle(built, heights, textures, tmp_path):
     side.tofile(tmp_path / "side.rgb")
     exe = str(tmp_path / "host_adapter_main")
     libdir = os.path.join(ROOT, "cpuvoxelraycaster_amd")
-    subprocess.check_call(["g++", "-std=c++14", "-O1", os.path.join(ROOT, "tests", "cpp", "host_adapter_main.cpp"),
-                           "-o", exe, "-L" + libdir, "-l:libvrc_hip.so", "-Wl,-rpath," + libdir])
+    subprocess.check_call(["g++", "-std=c++14", "-O1", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                           os.path.join(ROOT, "tests", "cpp", "host_adapter_main.cpp"),
+                           "-o", exe, "-L" + libdir, "-l:libvrc_hip.so", "-L/opt/rocm/lib", "-lamdhip64",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
     out = subprocess.run([exe, str(tmp_path / "nodes.bin"), str(depth), str(tmp_path / "top.rgb"),
                           str(tmp_path / "side.rgb"), str(W), str(H)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     m = re.search(r"autofocus hit=(\d) distance=(\S+) complexity=(\d+) normal=(\S+),(\S+),(\S+)", out.stdout)
     f = re.search(r"frame sum=(\d+) fnv=([0-9a-f]+) rays=(\d+) steps=(\d+)", out.stdout)
     assert m and f, out.stdout
+    assert "sharded equal=1" in out.stdout, out.stdout      # setShard + resolveShard + vrc_unpack_shards == unsharded
     # oracle: same autofocus ray, same frame
     S = float(1 << depth)
     rot = O.make_rotation(0.0, -0.5)
