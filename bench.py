@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--pitch", type=float, default=-0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--inflight", type=int, default=1, help="frames in flight per GPU (renderers / streams used round-robin)")
     ap.add_argument("--tuning", default="", help="blocks_per_cu,refill_threshold,chunk")
     ap.add_argument("--kernel", type=int, default=2,
                     help="frame kernel: 2 stage-synchronous per tile (default), 0 tile-phased with LDS job pool, 1 persistent mixed-stage")
@@ -133,89 +134,121 @@ def main():
     # main.cpp:59-88 on the GPU: FastNoise heights -> LSVO, straight into HBM (csrc/vrc_build_gpu.hip);
     # the LNode[] is resident from here on
     svo = vrc.LSVO.fromFastNoiseTerrain(depth, seed=1337, device=local_rank, textures=textures)
-    rc = vrc.RayCaster(svo, (W, H))
     light = vrc.reference_light(depth)
-    rc.setLightPosition(light)
-    rc.use_gi, rc.use_samples, rc.shadow_samples = bool(cfg["use_gi"]), True, 1
-    rc.gi_bounces = cfg.get("gi_bounces", 1)
     cam = vrc.reference_camera(depth, pitch=args.pitch, aperture=cfg["aperture"],
                                focal_length=(60.0 * (1 << depth) / 512.0 if cfg["aperture"] else 1.0))
-    stream = torch.cuda.current_stream().cuda_stream
     L = vrc.capi.load()
 
+    # `--inflight F` frames in flight per GPU: frame i uses renderer / stream / buffers i % F.  With F = 2 the end of
+    # one launch (its last work units finish at latency speed with most of the chip idle) overlaps the start of the
+    # next frame's launch, like the all-gather of frame i overlaps the render of frame i + 1.  Frames stay independent
+    # and complete in order; F = 1 is the plain one-stream loop.
+    F = max(1, args.inflight)
+
+    def make_renderer():
+        r = vrc.RayCaster(svo, (W, H))
+        r.setLightPosition(light)
+        r.use_gi, r.use_samples, r.shadow_samples = bool(cfg["use_gi"]), True, 1
+        r.gi_bounces = cfg.get("gi_bounces", 1)
+        return r
+
+    rcs = [make_renderer() for _ in range(F)]
+    tstreams = [torch.cuda.current_stream()] if F == 1 else [torch.cuda.Stream() for _ in range(F)]
     shard_bytes = L.vrc_shard_bytes(W, H, ROW_BLOCK, world)
     if world > 1:
-        # double-buffered so the all-gather of frame i (RCCL's stream) overlaps the render of frame i+1
-        mine = [torch.empty(shard_bytes, dtype=torch.uint8, device="cuda") for _ in range(2)]
-        gathered = [torch.empty(world * shard_bytes, dtype=torch.uint8, device="cuda") for _ in range(2)]
-        full = torch.empty(H * W * 4, dtype=torch.uint8, device="cuda")
+        # per slot: this rank's packed shard, the all-gathered shards, the composed frame
+        mine = [torch.empty(shard_bytes, dtype=torch.uint8, device="cuda") for _ in range(max(2, F))]
+        gathered = [torch.empty(world * shard_bytes, dtype=torch.uint8, device="cuda") for _ in range(max(2, F))]
+        full = [torch.empty(H * W * 4, dtype=torch.uint8, device="cuda") for _ in range(max(2, F))]
+    n_slots = max(2, F)
 
     ev_pairs = []
-    state = {"i": 0, "pending": None}
+    state = {"i": 0, "pending": [None] * n_slots, "last_slot": 0}
 
-    def finish_gather():
-        """wait for the outstanding all-gather and scatter it into the full frame"""
-        if state["pending"] is None:
+    def finish_gather(slot):
+        """wait (on the current stream) for the slot's outstanding all-gather and scatter it into the slot's frame"""
+        if state["pending"][slot] is None:
             return
-        work, slot = state["pending"]
-        if work is not None:
+        work = state["pending"][slot]
+        if work != "sync":
             work.wait()                                        # current stream waits for the collective
         vrc.capi.check(L.vrc_unpack_shards(vrc.capi.ptr(gathered[slot].data_ptr()), W, H, ROW_BLOCK, world,
-                                           vrc.capi.ptr(full.data_ptr()), vrc.capi.ptr(stream)))
-        state["pending"] = None
+                                           vrc.capi.ptr(full[slot].data_ptr()),
+                                           vrc.capi.ptr(torch.cuda.current_stream().cuda_stream)))
+        state["pending"][slot] = None
 
     def step(timed):
         # one frame = render (spp samples per pixel into the accumulators) + one pass that resolves this rank's
         # rows to RGBA8 (straight into the packed shard buffer for N > 1) and clears their accumulators for the
         # next frame (vrc_resolve_shard = samples_to_image + pack_shard + reset_samples)
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()
-        if world > 1:
-            rc.renderFrame(cam, spp=spp, stream=stream, row_block=ROW_BLOCK, shard_index=rank, shard_count=world)
-        else:
-            rc.renderFrame(cam, spp=spp, stream=stream)
-        e1.record()
-        if world > 1:
-            slot = state["i"] % 2
-            rc.resolveShard(ROW_BLOCK, rank, world, mine[slot].data_ptr(), reset=True, stream=stream)
-            if backend == "nccl":
-                # RCCL over xGMI: RGBA8 row-block shards; enqueued behind the resolve, runs beside the next render
-                work = dist.all_gather_into_tensor(gathered[slot], mine[slot], async_op=True)
+        i = state["i"]
+        rc, ts = rcs[i % F], tstreams[i % F]
+        slot = i % n_slots
+        with torch.cuda.stream(ts):
+            stream = ts.cuda_stream
+            if world > 1:
+                finish_gather(slot)                            # the frame that used this slot's buffers last
+            rc.frame_index = i * spp
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(ts)
+            if world > 1:
+                rc.renderFrame(cam, spp=spp, stream=stream, row_block=ROW_BLOCK, shard_index=rank, shard_count=world)
             else:
-                torch.cuda.current_stream().synchronize()
-                parts = [torch.empty_like(mine[slot]) for _ in range(world)]
-                dist.all_gather(parts, mine[slot])
-                gathered[slot].copy_(torch.cat(parts))
-                work = None
-            finish_gather()                                    # previous frame's gather -> full frame
-            state["pending"] = (work, slot)
-            state["i"] += 1
-        else:
-            rc.resolveShard(reset=True, stream=stream)
+                rc.renderFrame(cam, spp=spp, stream=stream)
+            e1.record(ts)
+            if world > 1:
+                rc.resolveShard(ROW_BLOCK, rank, world, mine[slot].data_ptr(), reset=True, stream=stream)
+                if backend == "nccl":
+                    # RCCL over xGMI: RGBA8 row-block shards; enqueued behind the resolve, runs beside the next render
+                    state["pending"][slot] = dist.all_gather_into_tensor(gathered[slot], mine[slot], async_op=True)
+                else:
+                    ts.synchronize()
+                    parts = [torch.empty_like(mine[slot]) for _ in range(world)]
+                    dist.all_gather(parts, mine[slot])
+                    gathered[slot].copy_(torch.cat(parts))
+                    state["pending"][slot] = "sync"
+                state["last_slot"] = slot
+            else:
+                rc.resolveShard(reset=True, stream=stream)
+        state["i"] += 1
         if timed:
             ev_pairs.append((e0, e1))
 
-    rc.resetSamples(stream)
+    def drain():
+        if world > 1:
+            torch.cuda.synchronize()                           # every frame stream has produced its shard
+            for k in range(n_slots):
+                finish_gather((state["i"] + k) % n_slots)      # oldest first; on the current stream
+        torch.cuda.synchronize()
+
+    for r in rcs:
+        r.resetSamples(tstreams[0].cuda_stream)
+    torch.cuda.synchronize()
     for _ in range(args.warmup):
         step(False)
-    if world > 1:
-        finish_gather()
-    rc.stats(reset=True, stream=stream)
+    drain()
+    for r in rcs:
+        r.stats(reset=True, stream=tstreams[0].cuda_stream)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
-    if world > 1:
-        finish_gather()                                        # the last frame's gather is inside the timed region
-    torch.cuda.synchronize()
+    drain()                                                    # the last frames' gathers are inside the timed region
     if world > 1:
         dist.barrier()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    st = rc.stats(stream=stream)
+    stream = tstreams[0].cuda_stream
+    sts = [r.stats(stream=stream) for r in rcs]
+
+    class _Sum:
+        rays = sum(x.rays for x in sts)
+        sum_complexity = sum(x.sum_complexity for x in sts)
+        pixels = sum(x.pixels for x in sts)
+    st = _Sum
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev_pairs) / max(1, len(ev_pairs))
 
     rays, steps_sum, pixels = st.rays, st.sum_complexity, st.pixels
@@ -235,15 +268,12 @@ def main():
     verified = None
     if world > 1 and rank == 0:
         # not timed: the gathered frame must equal the unsharded render of the same samples
-        ref = vrc.RayCaster(svo, (W, H))
-        ref.setLightPosition(light)
-        ref.use_gi, ref.use_samples, ref.shadow_samples = bool(cfg["use_gi"]), True, 1
-        ref.gi_bounces = cfg.get("gi_bounces", 1)
-        ref.frame_index = rc.frame_index - spp
+        ref = make_renderer()
+        ref.frame_index = (state["i"] - 1) * spp                 # the last frame rendered
         ref.renderFrame(cam, spp=spp, stream=stream)
         ref.samples_to_image(stream)
         torch.cuda.synchronize()
-        verified = bool(np.array_equal(full.cpu().numpy().reshape(H, W, 4), ref.readImage(stream)))
+        verified = bool(np.array_equal(full[state["last_slot"]].cpu().numpy().reshape(H, W, 4), ref.readImage(stream)))
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -275,7 +305,7 @@ def main():
             "config": {"workload": cfg["label"], "rays_per_frame": rays // args.steps,
                        "loop_iterations_per_frame": steps_sum // args.steps,
                        "camera_pitch": args.pitch, "lsvo_nodes": svo.n_nodes,
-                       "lsvo_gpu_build_ms": round(svo.build_ms, 3), "sharding": f"{ROW_BLOCK}-row blocks round-robin over {world} GPU(s)"
+                       "lsvo_gpu_build_ms": round(svo.build_ms, 3), "frames_in_flight": F, "sharding": f"{ROW_BLOCK}-row blocks round-robin over {world} GPU(s)"
                        + (", RCCL all-gather of RGBA8 shards" if world > 1 else ""),
                        "gathered_frame_equals_unsharded": verified},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
