@@ -109,16 +109,24 @@ def main():
     # one process per GPU; VRC_DIST_BACKEND=gloo (+ ranks sharing a GPU) exists only to exercise the
     # N > 1 code path on a single-GPU box -- the real run is nccl (= RCCL over xGMI)
     backend = os.environ.get("VRC_DIST_BACKEND", "nccl")
+    # VRC_FORCE_DIST=1 takes the N > 1 code path (process group, shard buffers, all-gather, unpack) with a world of one
+    # rank: the only way to run the RCCL calls of this file on a single-GPU box
+    dist_on = world > 1 or os.environ.get("VRC_FORCE_DIST") == "1"
+    if dist_on and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
     local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if dist_on:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
     # the in-tree libraries travel with the snapshot; if they are missing or stale, ONE process per node builds
     # (N ranks writing the same .so at once would corrupt it) and the others wait
-    if world > 1:
+    if dist_on:
         if local_rank == 0:
             g.build()
         dist.barrier()
@@ -155,7 +163,7 @@ def main():
     rcs = [make_renderer() for _ in range(F)]
     tstreams = [torch.cuda.current_stream()] if F == 1 else [torch.cuda.Stream() for _ in range(F)]
     shard_bytes = L.vrc_shard_bytes(W, H, ROW_BLOCK, world)
-    if world > 1:
+    if dist_on:
         # per slot: this rank's packed shard, the all-gathered shards, the composed frame
         mine = [torch.empty(shard_bytes, dtype=torch.uint8, device="cuda") for _ in range(max(2, F))]
         gathered = [torch.empty(world * shard_bytes, dtype=torch.uint8, device="cuda") for _ in range(max(2, F))]
@@ -186,18 +194,18 @@ def main():
         slot = i % n_slots
         with torch.cuda.stream(ts):
             stream = ts.cuda_stream
-            if world > 1:
+            if dist_on:
                 finish_gather(slot)                            # the frame that used this slot's buffers last
             rc.frame_index = i * spp
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
             e0.record(ts)
-            if world > 1:
+            if dist_on:
                 rc.renderFrame(cam, spp=spp, stream=stream, row_block=ROW_BLOCK, shard_index=rank, shard_count=world)
             else:
                 rc.renderFrame(cam, spp=spp, stream=stream)
             e1.record(ts)
-            if world > 1:
+            if dist_on:
                 rc.resolveShard(ROW_BLOCK, rank, world, mine[slot].data_ptr(), reset=True, stream=stream)
                 if backend == "nccl":
                     # RCCL over xGMI: RGBA8 row-block shards; enqueued behind the resolve, runs beside the next render
@@ -216,7 +224,7 @@ def main():
             ev_pairs.append((e0, e1))
 
     def drain():
-        if world > 1:
+        if dist_on:
             torch.cuda.synchronize()                           # every frame stream has produced its shard
             for k in range(n_slots):
                 finish_gather((state["i"] + k) % n_slots)      # oldest first; on the current stream
@@ -230,14 +238,14 @@ def main():
     drain()
     for r in rcs:
         r.stats(reset=True, stream=tstreams[0].cuda_stream)
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
     drain()                                                    # the last frames' gathers are inside the timed region
-    if world > 1:
+    if dist_on:
         dist.barrier()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -252,7 +260,7 @@ def main():
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev_pairs) / max(1, len(ev_pairs))
 
     rays, steps_sum, pixels = st.rays, st.sum_complexity, st.pixels
-    if world > 1:
+    if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -266,7 +274,7 @@ def main():
         kernel_ms_max = kernel_ms
 
     verified = None
-    if world > 1 and rank == 0:
+    if dist_on and rank == 0:
         # not timed: the gathered frame must equal the unsharded render of the same samples
         ref = make_renderer()
         ref.frame_index = (state["i"] - 1) * spp                 # the last frame rendered
@@ -306,7 +314,7 @@ def main():
                        "loop_iterations_per_frame": steps_sum // args.steps,
                        "camera_pitch": args.pitch, "lsvo_nodes": svo.n_nodes,
                        "lsvo_gpu_build_ms": round(svo.build_ms, 3), "frames_in_flight": F, "sharding": f"{ROW_BLOCK}-row blocks round-robin over {world} GPU(s)"
-                       + (", RCCL all-gather of RGBA8 shards" if world > 1 else ""),
+                       + (", RCCL all-gather of RGBA8 shards" if dist_on else ""),
                        "gathered_frame_equals_unsharded": verified},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
@@ -315,10 +323,16 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, svo.downloadNodes(), textures, cam, light)
-        print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes its version banner to the C stdout buffer, which is flushed at exit, i.e. after anything Python
+        # printed: flush it first so that the JSON line is the last line of stdout
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
