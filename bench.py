@@ -10,6 +10,16 @@ frame kernel, the sample resolve, and -- for N > 1 -- the row-block shard pack,
 the RCCL all-gather of the RGBA8 framebuffer and the unpack.  rays = traversals
 actually executed (counted by the kernel, equal to the oracle's count).
 
+Frames are independent.  On one GPU they are issued on one stream, each after
+the other (`--inflight 1`: ms_per_step is a frame latency and a launch never
+shares the chip, which keeps the per-launch roofline clean).  On several GPUs a
+rank's shard is small and its launch is mostly tail -- the last work units finish
+at latency speed with most of the chip idle -- so there two renderers / streams
+alternate (`--inflight 2`) and the end of one launch overlaps the start of the
+next frame, just as the all-gather of frame i overlaps the renders after it;
+ms_per_step is then the steady-state frame period.  `config.frames_in_flight`
+says which was used.
+
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
@@ -85,7 +95,9 @@ def main():
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--pitch", type=float, default=-0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--inflight", type=int, default=1, help="frames in flight per GPU (renderers / streams used round-robin)")
+    ap.add_argument("--inflight", type=int, default=0,
+                    help="frames in flight per GPU (renderers / streams used round-robin); 1 = one stream, each frame starts "
+                         "when the previous one has ended; 0 = automatic: 1 on one GPU, 2 on several")
     ap.add_argument("--tuning", default="", help="blocks_per_cu,refill_threshold,chunk")
     ap.add_argument("--kernel", type=int, default=2,
                     help="frame kernel: 2 stage-synchronous per tile (default), 0 tile-phased with LDS job pool, 1 persistent mixed-stage")
@@ -151,7 +163,7 @@ def main():
     # one launch (its last work units finish at latency speed with most of the chip idle) overlaps the start of the
     # next frame's launch, like the all-gather of frame i overlaps the render of frame i + 1.  Frames stay independent
     # and complete in order; F = 1 is the plain one-stream loop.
-    F = max(1, args.inflight)
+    F = args.inflight if args.inflight > 0 else (2 if dist_on else 1)
 
     def make_renderer():
         r = vrc.RayCaster(svo, (W, H))
@@ -165,10 +177,12 @@ def main():
     shard_bytes = L.vrc_shard_bytes(W, H, ROW_BLOCK, world)
     if dist_on:
         # per slot: this rank's packed shard, the all-gathered shards, the composed frame
-        mine = [torch.empty(shard_bytes, dtype=torch.uint8, device="cuda") for _ in range(max(2, F))]
-        gathered = [torch.empty(world * shard_bytes, dtype=torch.uint8, device="cuda") for _ in range(max(2, F))]
-        full = [torch.empty(H * W * 4, dtype=torch.uint8, device="cuda") for _ in range(max(2, F))]
-    n_slots = max(2, F)
+        mine = [torch.empty(shard_bytes, dtype=torch.uint8, device="cuda") for _ in range(F + 1)]
+        gathered = [torch.empty(world * shard_bytes, dtype=torch.uint8, device="cuda") for _ in range(F + 1)]
+        full = [torch.empty(H * W * 4, dtype=torch.uint8, device="cuda") for _ in range(F + 1)]
+    # one slot more than frames in flight: a frame's all-gather is only waited for when its slot comes round again,
+    # F frames later, so that wait never holds up the frame being issued
+    n_slots = F + 1
 
     ev_pairs = []
     state = {"i": 0, "pending": [None] * n_slots, "last_slot": 0}
