@@ -177,12 +177,13 @@ def main():
     shard_bytes = L.vrc_shard_bytes(W, H, ROW_BLOCK, world)
     if dist_on:
         # per slot: this rank's packed shard, the all-gathered shards, the composed frame
-        mine = [torch.empty(shard_bytes, dtype=torch.uint8, device="cuda") for _ in range(F + 1)]
-        gathered = [torch.empty(world * shard_bytes, dtype=torch.uint8, device="cuda") for _ in range(F + 1)]
-        full = [torch.empty(H * W * 4, dtype=torch.uint8, device="cuda") for _ in range(F + 1)]
-    # one slot more than frames in flight: a frame's all-gather is only waited for when its slot comes round again,
-    # F frames later, so that wait never holds up the frame being issued
-    n_slots = F + 1
+        mine = [torch.empty(shard_bytes, dtype=torch.uint8, device="cuda") for _ in range(2 if F == 1 else F + 2)]
+        gathered = [torch.empty(world * shard_bytes, dtype=torch.uint8, device="cuda") for _ in range(2 if F == 1 else F + 2)]
+        full = [torch.empty(H * W * 4, dtype=torch.uint8, device="cuda") for _ in range(2 if F == 1 else F + 2)]
+    # more slots than frames in flight: a frame's all-gather is only waited for when its slot comes round again, so that
+    # wait does not hold up the frame being issued (with two frames in flight a frame's resolve pass only gets onto the
+    # chip when the next frame's launch starts to drain, and its all-gather runs after that)
+    n_slots = 2 if F == 1 else F + 2
 
     ev_pairs = []
     state = {"i": 0, "pending": [None] * n_slots, "last_slot": 0}
