@@ -366,7 +366,9 @@ extern "C" int vrc_render_frame(vrc_renderer* r, const vrc_camera* cam, const vr
     } else {
         a.p.row_block = 0; a.p.shard_index = 0; a.p.shard_count = 1;
     }
-    const uint32_t tiles_per_row = (r->width + 7u) / 8u;
+    // checkerboard frames on the stage-synchronous kernel: 16 x 8 pixel tiles, 64 selected pixels each
+    a.checker_wide = (g_tuning.kernel == VRC_KERNEL_SYNC && p->checker_parity >= 0) ? 1u : 0u;
+    const uint32_t tiles_per_row = a.checker_wide ? (r->width + 15u) / 16u : (r->width + 7u) / 8u;
     const uint64_t items = (uint64_t)tiles_per_row * ((rows + 7u) / 8u) * 64ull;
     if (items > 0xfffffff0ull) return fail(VRC_ERR_INVALID, "vrc_render_frame: frame too large");
     a.n_items = (uint32_t)items;

@@ -50,6 +50,7 @@ struct FrameArgs {
     uint32_t refill_threshold;// leave the traversal loop once this many lanes wait
     uint32_t sample_chunk;    // k_render_sync: samples per work unit (0 = all spp in one unit)
     uint32_t sample_chunk_tail, tail_tiles;   // ... and for the last `tail_tiles` tiles (0 = same chunk)
+    uint32_t checker_wide;    // k_render_sync, checkerboard frames: tiles are 16 x 8 pixels, every lane takes a selected pixel
     vrc_camera cam;
     vrc_frame_params p;
 };

@@ -861,7 +861,10 @@ k_render_sync(const FrameArgs a)
     const uint32_t shadow_samples = a.p.shadow_samples ? a.p.shadow_samples : (a.p.use_samples ? 4u : 1u);
     const uint32_t gi_bounces = a.p.gi_bounces ? a.p.gi_bounces : 1u;
     const uint32_t spp = a.p.spp ? a.p.spp : 1u;
-    const uint32_t tiles_per_row = (W + 7u) / 8u;
+    // Checkerboard frames (main.cpp:137,143: every other pixel of each swarm area) use tiles of 16 x 8 pixels, of
+    // which a lane takes the selected pixel of its pair, so that all 64 lanes of a wave have work
+    const bool checker = a.checker_wide != 0u;
+    const uint32_t tiles_per_row = checker ? (W + 15u) / 16u : (W + 7u) / 8u;
     const uint32_t n_tiles = a.n_items >> 6;
     const bool sharded = a.p.row_block && a.p.shard_count > 1u;
     // Pinhole camera (aperture exactly +0, the reference's default): rand_vec = 0 * getRand() is +-0, which changes
@@ -935,9 +938,14 @@ k_render_sync(const FrameArgs a)
         const uint32_t tile = (in_tail ? head_tiles : 0u) + u / chunks_per_tile;
         const uint32_t s_begin = (u % chunks_per_tile) * chunk, s_end = min(spp, s_begin + chunk);
         const uint32_t tx = tile % tiles_per_row, ty = tile / tiles_per_row;
-        const uint32_t px_x = tx * 8u + (lane & 7u);
+        uint32_t px_x = tx * 8u + (lane & 7u);
         uint32_t px_y = ty * 8u + (lane >> 3);
         if (sharded) px_y = ((px_y / a.p.row_block) * a.p.shard_count + a.p.shard_index) * a.p.row_block + (px_y % a.p.row_block);
+        if (checker) {
+            // the pixel of the pair (2c, 2c + 1) that pixel_selected accepts in this row: x = (y - y0 + parity) mod 2
+            const uint32_t ah = H / 4u, y0 = ah ? (px_y / ah) * ah : 0u;
+            px_x = tx * 16u + 2u * (lane & 7u) + ((px_y - y0 + (uint32_t)a.p.checker_parity) & 1u);
+        }
         const bool valid = px_x < W && px_y < H && pixel_selected(a.p, W, H, px_x, px_y);
         const uint32_t pix = px_y * W + px_x;
         uint32_t acc_r = 0u, acc_g = 0u, acc_b = 0u;

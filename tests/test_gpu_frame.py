@@ -122,6 +122,15 @@ def test_temporal_blend_checkerboard(scene, textures):
     run_pair(scene, textures, 9, 320, 180, -0.5, frames=4, use_gi=1, use_samples=0, checker=True)
 
 
+@pytest.mark.parametrize("size", [(161, 93), (50, 38), (7, 5), (16, 8), (17, 9)])
+@pytest.mark.parametrize("use_samples", [0, 1])
+def test_checkerboard_sizes(scene, textures, size, use_samples):
+    """Checkerboard frames (main.cpp:137,143: every other pixel inside each of the 4 x 4 swarm areas) at sizes that are
+    not multiples of the 16 x 8 tiles the stage-synchronous kernel uses for them, both sinks, alternating parity."""
+    run_pair(scene, textures, 7, size[0], size[1], -0.5, frames=3, spp=1 + use_samples, use_gi=1, use_samples=use_samples,
+             checker=True)
+
+
 def test_odd_sizes(scene, textures):
     run_pair(scene, textures, 7, 161, 93, -0.8, spp=2, use_gi=1)
     run_pair(scene, textures, 7, 7, 5, -0.8, spp=1, use_gi=0)
@@ -166,6 +175,44 @@ def test_sharded_frames_compose(scene, textures):
     torch.cuda.synchronize()
     assert np.array_equal(out.cpu().numpy().reshape(H, W, 4), ref)
     assert total_rays == full.stats().rays
+
+
+@pytest.mark.parametrize("parity", [0, 1])
+def test_sharded_checkerboard_frames_compose(scene, textures, parity):
+    """Sharding and the checkerboard together (the 16 x 8 checkerboard tiles are laid over the shard's compact rows,
+    the checker pattern follows the global row): 3 shards composed == the unsharded checkerboard frame."""
+    import torch
+    import cpuvoxelraycaster_amd as vrc
+    nodes, svo = scene[7]
+    W, H, RB, N = 203, 101, 8, 3
+    light = vrc.reference_light(7)
+    cam = vrc.reference_camera(7, pitch=-0.5)
+
+    def make():
+        rc = vrc.RayCaster(svo, (W, H))
+        rc.setLightPosition(light)
+        rc.use_gi = rc.use_samples = True
+        rc.shadow_samples = 1
+        return rc
+
+    full = make()
+    full.renderFrame(cam, spp=2, checker_parity=parity)
+    full.samples_to_image()
+    ref = full.readImage()
+    L = vrc.capi.load()
+    nbytes = L.vrc_shard_bytes(W, H, RB, N)
+    gathered = torch.zeros(N * nbytes, dtype=torch.uint8, device="cuda")
+    rays = 0
+    for k in range(N):
+        rc = make()
+        rc.renderFrame(cam, spp=2, checker_parity=parity, row_block=RB, shard_index=k, shard_count=N)
+        rc.resolveShard(RB, k, N, gathered.data_ptr() + k * nbytes, reset=True)
+        rays += rc.stats().rays
+    out = torch.zeros(H * W * 4, dtype=torch.uint8, device="cuda")
+    vrc.capi.check(L.vrc_unpack_shards(vrc.capi.ptr(gathered.data_ptr()), W, H, RB, N, vrc.capi.ptr(out.data_ptr()), None))
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy().reshape(H, W, 4), ref)
+    assert rays == full.stats().rays and rays > 0
 
 
 def test_resolve_shard_equals_resolve_pack_reset(scene, textures):
