@@ -86,17 +86,22 @@ def main():
                                   focal_length=float(rng.uniform(1, 120)))
             spp = int(rng.integers(1, 7))
             nfr = int(rng.integers(1, 3))
-            checker = bool(rng.integers(0, 2)) and not use_samples
+            checker = bool(rng.integers(0, 2))
+            # a third of the frames are one rank's shard of a multi-GPU frame
+            shard_count = int(rng.choice([1, 1, 2, 3, 5]))
+            shard_index = int(rng.integers(0, shard_count))
+            row_block = int(rng.choice([8, 8, 4, 16, 5])) if shard_count > 1 else 0
             ocam = O.make_camera(tuple(cam.position), tuple(cam.rot), cam.fov, cam.aperture, cam.focal_length)
             oimg = oacc = None
             rr = ss = 0
             fi = 0
             for f in range(nfr):
                 par = (f % 2) if checker else -1
-                rc.renderFrame(cam, spp=spp, checker_parity=par)
+                rc.renderFrame(cam, spp=spp, checker_parity=par, row_block=row_block, shard_index=shard_index, shard_count=shard_count)
                 for s in range(spp):
                     p = O.make_params(W, H, light, use_gi=int(rc.use_gi), use_samples=use_samples, shadow_samples=rc.shadow_samples,
-                                      gi_bounces=rc.gi_bounces, checker_parity=par, seed=rc.seed, frame_index=fi)
+                                      gi_bounces=rc.gi_bounces, checker_parity=par, seed=rc.seed, frame_index=fi,
+                                      row_block=row_block, shard_index=shard_index, shard_count=shard_count)
                     oimg, oacc, _, st = O.render_frame(nodes, depth, top, side, ocam, p, image=oimg, accum=oacc, threads=16)
                     rr += st.rays; ss += st.sum_complexity; fi += 1
             st = rc.stats()
@@ -105,7 +110,8 @@ def main():
             frames += 1
             rays_total += rr
             if not ok:
-                print("FRAME MISMATCH", it, dict(depth=depth, W=W, H=H, kernel=kernel, spp=spp, gi=rc.use_gi, samples=use_samples)); bad += 1
+                print("FRAME MISMATCH", it, dict(depth=depth, W=W, H=H, kernel=kernel, spp=spp, gi=rc.use_gi, samples=use_samples,
+                                                 checker=checker, shard=(row_block, shard_index, shard_count))); bad += 1
             vrc.capi.check(L.vrc_set_kernel(2)); vrc.capi.check(L.vrc_set_sample_chunk(0))
     print(f"fuzz: {it} cases ({frames} frames), {rays_total} rays compared, {bad} mismatches, {time.time() - t0:.0f} s")
     sys.exit(1 if bad else 0)
