@@ -90,7 +90,7 @@ def main():
             # a third of the frames are one rank's shard of a multi-GPU frame
             shard_count = int(rng.choice([1, 1, 2, 3, 5]))
             shard_index = int(rng.integers(0, shard_count))
-            row_block = int(rng.choice([8, 8, 4, 16, 5])) if shard_count > 1 else 0
+            row_block = int(rng.choice([8, 8, 16, 24])) if shard_count > 1 else 0
             ocam = O.make_camera(tuple(cam.position), tuple(cam.rot), cam.fov, cam.aperture, cam.focal_length)
             oimg = oacc = None
             rr = ss = 0
