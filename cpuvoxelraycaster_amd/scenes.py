@@ -11,7 +11,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def load_terrain_heights():
     """int32 height[x, z] of main.cpp:69 for x, z < 1024 (fixture generated from
-    the reference's vendored FastNoise by tools/make_golden.py)."""
+    the reference's vendored FastNoise by tests/tools/make_golden.py)."""
     return np.load(os.path.join(GOLDEN, "terrain_height_1024.npz"))["height"].astype(np.int32)
 
 

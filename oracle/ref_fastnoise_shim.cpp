@@ -1,7 +1,7 @@
 // Calls the REAL vendored FastNoise of the reference (compiled from
 // /root/reference/lib/fastnoise/FastNoise.cpp where it lies -- see Makefile)
 // exactly the way the reference's scene generator does (src/main.cpp:61-69).
-// Test infrastructure: used by tools/make_golden.py to produce the terrain
+// Test infrastructure: used by tests/tools/make_golden.py to produce the terrain
 // height fixture.  Contains no reference code, only the calls.
 #include "FastNoise.h"
 #include <cstdint>

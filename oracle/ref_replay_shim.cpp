@@ -1,6 +1,6 @@
 // Calls the REAL replay reader of the reference (include/replay.hpp, which needs nothing but the
 // standard library) compiled from where it lies -- see Makefile.  Test infrastructure: used by
-// tools/make_golden_replay.py to produce tests/golden/replay_cases.json and by the pin test where
+// tests/tools/make_golden_replay.py to produce tests/golden/replay_cases.json and by the pin test where
 // /root/reference is mounted.  Contains no reference code, only the call.
 #include "replay.hpp"
 #include <cstdint>

@@ -14,11 +14,11 @@
  *   - terrain heights: the restated SimplexFractal noise (orc_terrain_heights)
  *     equals, for all 1024 x 1024 columns, the output of the real vendored
  *     FastNoise compiled from /root/reference (oracle/_ref, oracle/Makefile,
- *     tools/make_golden.py -> tests/golden/terrain_height_1024.npz) -- this row
+ *     tests/tools/make_golden.py -> tests/golden/terrain_height_1024.npz) -- this row
  *     is pinned by reference execution;
  *   - the camera-path replay reader (include/replay.hpp, standard library only) is compiled where it lies into
  *     oracle/_ref/libref_replay.so; what it parses from a set of replay texts is the fixture
- *     tests/golden/replay_cases.json (tools/make_golden_replay.py) -- pinned by reference execution too;
+ *     tests/golden/replay_cases.json (tests/tools/make_golden_replay.py) -- pinned by reference execution too;
  *   - the restated builder + traversal reproduce the statistics SURVEY.md
  *     App. B measured on the unmodified reference (node count 10 528 393 at
  *     512^3, first nodes, level histogram, per-pose hit counts, mean / max

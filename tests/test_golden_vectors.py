@@ -1,4 +1,4 @@
-"""Committed regression vectors (tools/make_golden_vectors.py): the oracle must keep
+"""Committed regression vectors (tests/tools/make_golden_vectors.py): the oracle must keep
 producing them (CPU), and the HIP path must reproduce them on the GPU box where
 /root/reference -- and therefore nothing but these fixtures -- exists."""
 import json

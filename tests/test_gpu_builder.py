@@ -62,7 +62,7 @@ def test_builder_1024_properties(built, heights):
 
 def test_gpu_noise_matches_real_fastnoise(built, heights):
     """N4, pinned by reference execution: the GPU terrain-height kernel against the
-    fixture produced by the reference's own FastNoise.cpp (tools/make_golden.py)."""
+    fixture produced by the reference's own FastNoise.cpp (tests/tools/make_golden.py)."""
     import ctypes as C
     import cpuvoxelraycaster_amd as vrc
     h = np.zeros((1024, 1024), np.int32)

@@ -249,7 +249,7 @@ def _host_replay_reader(tmp_path):
 
 def test_replay_reader_pinned_by_reference_execution(built, tmp_path):
     """N3: tests/golden/replay_cases.json holds what the reference's own ReplayElements::loadFromFile
-    (include/replay.hpp, compiled where it lies: oracle/_ref/libref_replay.so, tools/make_golden_replay.py) parses from
+    (include/replay.hpp, compiled where it lies: oracle/_ref/libref_replay.so, tests/tools/make_golden_replay.py) parses from
     a set of replay texts -- ticks spanning lines, numbers glued to text, truncated and malformed ticks, float32
     overflow, nan / hex words.  The host adapter's reader and the Python replay driver must return the same ticks bit
     for bit; where /root/reference is mounted the live reference reader is checked against the fixture too."""
