@@ -136,27 +136,39 @@ __global__ void k_fill_blank_nodes(uint2* __restrict__ nodes, uint64_t n)
 
 inline dim3 grid_for(uint64_t n) { return dim3((uint32_t)((n + 255) / 256)); }
 
-template <class Vox>
-int build_on_device(Vox vox, uint32_t depth, int device, int cus, vrc_scene** out, float* ms_out)
+// `pre` (optional) enqueues the kernels that produce the occupancy source (noise, column limits); it runs inside the
+// timed region.  *ms_out = device time of the build: [pre + count sweep] + [blank fill + emit sweep], two event
+// pairs around the enqueued kernels; the per-level grids come from ONE allocation made before the first event,
+// and the node array's allocation (its size is the count sweep's result) lies between the pairs -- neither is timed.
+template <class Vox, class Pre>
+int build_on_device(Vox vox, uint32_t depth, int device, int cus, vrc_scene** out, float* ms_out, Pre pre)
 {
     int rc = VRC_OK;
     const uint32_t N = depth;
     std::vector<uint32_t*> cnt(N, nullptr), rank(N, nullptr), index(N, nullptr);
+    uint32_t* arena = nullptr;
     void* d_nodes = nullptr;
     void* d_tex = nullptr;
     vrc_scene* s = nullptr;
     uint32_t root_cnt = 0;
-    uint64_t n_nodes = 0;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    HIP_TRYB(hipEventCreate(&e0));
-    HIP_TRYB(hipEventCreate(&e1));
-    HIP_TRYB(hipEventRecord(e0, nullptr));
-    for (uint32_t L = 0; L < N; ++L) {
-        const uint64_t cells = 1ull << (3 * L);
-        HIP_TRYB(hipMalloc((void**)&cnt[L], cells * 4));
-        HIP_TRYB(hipMalloc((void**)&rank[L], cells * 4));
-        HIP_TRYB(hipMalloc((void**)&index[L], cells * 4));
+    uint64_t n_nodes = 0, total_cells = 0;
+    float ms_count = 0.0f, ms_emit = 0.0f;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (int i = 0; i < 4; ++i) HIP_TRYB(hipEventCreate(&ev[i]));
+    for (uint32_t L = 0; L < N; ++L) total_cells += 1ull << (3 * L);
+    HIP_TRYB(hipMalloc((void**)&arena, total_cells * 12));
+    {
+        uint64_t off = 0;
+        for (uint32_t L = 0; L < N; ++L) {
+            const uint64_t cells = 1ull << (3 * L);
+            cnt[L] = arena + off; rank[L] = arena + total_cells + off; index[L] = arena + 2 * total_cells + off;
+            off += cells;
+        }
     }
+    HIP_TRYB(hipMemsetAsync(rank[0], 0, 4, nullptr));
+    HIP_TRYB(hipMemsetAsync(index[0], 0, 4, nullptr));
+    HIP_TRYB(hipEventRecord(ev[0], nullptr));
+    HIP_TRYB(pre());
     // bottom-up counts
     {
         const uint32_t n = 1u << (N - 1);
@@ -167,18 +179,19 @@ int build_on_device(Vox vox, uint32_t depth, int device, int cus, vrc_scene** ou
         }
         HIP_TRYB(hipGetLastError());
     }
+    HIP_TRYB(hipEventRecord(ev[1], nullptr));
     HIP_TRYB(hipMemcpy(&root_cnt, cnt[0], 4, hipMemcpyDeviceToHost));
     n_nodes = 1ull + 8ull * root_cnt;                 // data = { root } + 8 slots per internal node
     if (n_nodes > VRC_MAX_NODES) { rc = vrc::fail(VRC_ERR_INVALID, "scene needs more than 2^29 nodes (4 GiB)"); goto done; }
     HIP_TRYB(hipMalloc(&d_nodes, n_nodes * sizeof(vrc_lnode)));
+    HIP_TRYB(hipMalloc(&d_tex, 1536));
+    HIP_TRYB(hipEventRecord(ev[2], nullptr));
     hipLaunchKernelGGL(k_fill_blank_nodes, grid_for(n_nodes), dim3(256), 0, nullptr, (uint2*)d_nodes, n_nodes);
     if (root_cnt == 0) {
         // empty scene: compileSVO_rec still stores child_offset = 1 in the root (:8-10) and appends nothing
         const vrc_lnode root = {1u, 0u, 0u, 0u, 1u};
         HIP_TRYB(hipMemcpy(d_nodes, &root, sizeof(root), hipMemcpyHostToDevice));
     } else {
-        HIP_TRYB(hipMemset(rank[0], 0, 4));
-        HIP_TRYB(hipMemset(index[0], 0, 4));
         for (uint32_t L = 0; L < N; ++L) {
             const uint32_t n = 1u << L;
             const uint64_t cells = (uint64_t)n * n * n;
@@ -191,10 +204,11 @@ int build_on_device(Vox vox, uint32_t depth, int device, int cus, vrc_scene** ou
         }
         HIP_TRYB(hipGetLastError());
     }
-    HIP_TRYB(hipEventRecord(e1, nullptr));
-    HIP_TRYB(hipEventSynchronize(e1));
-    if (ms_out) HIP_TRYB(hipEventElapsedTime(ms_out, e0, e1));
-    HIP_TRYB(hipMalloc(&d_tex, 1536));
+    HIP_TRYB(hipEventRecord(ev[3], nullptr));
+    HIP_TRYB(hipEventSynchronize(ev[3]));
+    HIP_TRYB(hipEventElapsedTime(&ms_count, ev[0], ev[1]));
+    HIP_TRYB(hipEventElapsedTime(&ms_emit, ev[2], ev[3]));
+    if (ms_out) *ms_out = ms_count + ms_emit;
     HIP_TRYB(hipMemset(d_tex, 0xff, 1536));
     s = (vrc_scene*)calloc(1, sizeof(vrc_scene));
     if (!s) { rc = vrc::fail(VRC_ERR_OOM, "out of host memory"); goto done; }
@@ -202,11 +216,10 @@ int build_on_device(Vox vox, uint32_t depth, int device, int cus, vrc_scene** ou
     d_nodes = nullptr; d_tex = nullptr;
     *out = s;
 done:
-    for (uint32_t L = 0; L < N; ++L) { (void)hipFree(cnt[L]); (void)hipFree(rank[L]); (void)hipFree(index[L]); }
+    if (arena) (void)hipFree(arena);
     if (d_nodes) (void)hipFree(d_nodes);
     if (d_tex) (void)hipFree(d_tex);
-    if (e0) (void)hipEventDestroy(e0);
-    if (e1) (void)hipEventDestroy(e1);
+    for (int i = 0; i < 4; ++i) if (ev[i]) (void)hipEventDestroy(ev[i]);
     return rc;
 }
 
@@ -218,6 +231,15 @@ done:
 // whole chain noise -> heights -> LSVO -> frames stays in HBM.  Bit-identical to
 // the real FastNoise (tests compare with heights produced by the reference's own
 // FastNoise.cpp).  All float operations in the reference's order, no contraction.
+//
+// The noise ALGORITHM restated here (seeded permutation, 2-D simplex, FBM) is FastNoise's:
+//   FastNoise -- MIT License -- Copyright (c) 2017 Jordan Peck
+//   Permission is hereby granted, free of charge, to any person obtaining a copy of this software and associated
+//   documentation files (the "Software"), to deal in the Software without restriction, including without limitation
+//   the rights to use, copy, modify, merge, publish, distribute, sublicense, and/or sell copies of the Software,
+//   and to permit persons to whom the Software is furnished to do so, subject to the following conditions: The
+//   above copyright notice and this permission notice shall be included in all copies or substantial portions of
+//   the Software.  THE SOFTWARE IS PROVIDED "AS IS", WITHOUT WARRANTY OF ANY KIND.
 // ---------------------------------------------------------------------------
 namespace {
 
@@ -226,59 +248,69 @@ struct NoiseTables {
     float F2, G2, two_G2, bounding;
 };
 
-// FastNoise::SetSeed (FastNoise.cpp:197-215) + the constants of :1270-1272 and
-// CalculateFractalBounding (:217-227, gain 0.5, 3 octaves).  Host side.
+// The permutation the reference's FastNoise builds for a seed (FastNoise::SetSeed, FastNoise.cpp:197-215): a
+// Fisher-Yates pass over the identity, position `done` drawing its partner from the not yet fixed tail with
+// std::mt19937_64 (one draw per position, modulo the tail length); both tables are stored twice so that
+// perm[a + perm[b]] needs no wrap.  Plus the 2-D simplex skew constants (:1270-1272) and the FBM normaliser
+// (CalculateFractalBounding, :217-227: gain 0.5, 3 octaves).  Host side.
 void noise_tables(int seed, NoiseTables& t)
 {
-    std::mt19937_64 gen(seed);
-    for (int i = 0; i < 256; i++) t.perm[i] = (uint8_t)i;
-    for (int j = 0; j < 256; j++) {
-        const int rng = (int)(gen() % (256 - j));
-        const int k = rng + j;
-        const int l = t.perm[j];
-        t.perm[j] = t.perm[j + 256] = t.perm[k];
-        t.perm[k] = (uint8_t)l;
-        t.perm12[j] = t.perm12[j + 256] = (uint8_t)(t.perm[j] % 12);
+    std::mt19937_64 draw(seed);
+    uint8_t order[256];
+    for (unsigned v = 0; v < 256u; ++v) order[v] = (uint8_t)v;
+    for (unsigned done = 0; done < 256u; ++done) {
+        const unsigned pick = done + (unsigned)((int)(draw() % (256u - done)));
+        const uint8_t fixed = order[pick];
+        order[pick] = order[done];
+        order[done] = fixed;
     }
-    const volatile float SQRT3 = 1.7320508075688772935274463415059f;
-    t.F2 = 0.5f * (SQRT3 - 1.0f);
-    t.G2 = (3.0f - SQRT3) / 6.0f;
+    for (unsigned v = 0; v < 256u; ++v) {
+        t.perm[v] = t.perm[v + 256u] = order[v];
+        t.perm12[v] = t.perm12[v + 256u] = (uint8_t)(order[v] % 12u);
+    }
+    const volatile float root3 = 1.7320508075688772935274463415059f;
+    t.F2 = 0.5f * (root3 - 1.0f);
+    t.G2 = (3.0f - root3) / 6.0f;
     t.two_G2 = 2.0f * t.G2;
-    float amp = 0.5f, amp_fractal = 1.0f;
-    for (int i = 1; i < 3; i++) { amp_fractal += amp; amp *= 0.5f; }
-    t.bounding = 1.0f / amp_fractal;
+    float octave_gain = 0.5f, total = 1.0f;                // 1 + 0.5 + 0.25
+    for (int octave = 1; octave < 3; ++octave) { total += octave_gain; octave_gain *= 0.5f; }
+    t.bounding = 1.0f / total;
 }
 
 __device__ __forceinline__ int fn_fast_floor(float f) { return f >= 0 ? (int)f : (int)f - 1; }   // FastNoise.cpp:184
 
-__device__ __forceinline__ float fn_grad2(const uint8_t* perm, const uint8_t* perm12, uint32_t offset, int x, int y, float xd, float yd)
+// One simplex corner's term: falloff (0.5 - |d|^2)^4 times the gradient picked by the doubly indexed permutation
+// (Index2D_12, FastNoise.cpp:244-247; GradCoord2D, :312-317).  The 12 gradients (GRAD_X / GRAD_Y, :37-48, two
+// tables there) are decoded from the index instead: entries 0-3 are the four diagonals (+-1, +-1), 4-7 are
+// (+-1, 0) and 8-11 are (0, +-1), the sign alternating with the index.  A corner outside the falloff radius
+// contributes exactly +0.
+__device__ __forceinline__ float fn_corner2(const uint8_t* perm, const uint8_t* perm12, uint32_t offset, int cell_x, int cell_y,
+                                            float dx, float dy)
 {
-    // Index2D_12 (:244-247) + GradCoord2D (:312-317); GRAD_X / GRAD_Y (:37-48) as selects
-    const uint32_t lut = perm12[(x & 0xff) + perm[(y & 0xff) + offset]];
-    const float gx = lut >= 8u ? 0.0f : ((lut & 1u) ? -1.0f : 1.0f);
-    const float gy = lut < 4u ? ((lut & 2u) ? -1.0f : 1.0f) : (lut < 8u ? 0.0f : ((lut & 1u) ? -1.0f : 1.0f));
-    return xd * gx + yd * gy;
+    float fall = 0.5f - dx * dx - dy * dy;
+    if (fall < 0) return 0.0f;
+    const uint32_t g = perm12[(cell_x & 0xff) + perm[(cell_y & 0xff) + offset]];
+    const float odd = (g & 1u) ? -1.0f : 1.0f;
+    const float gx = g >= 8u ? 0.0f : odd;
+    const float gy = g >= 8u ? odd : (g >= 4u ? 0.0f : ((g & 2u) ? -1.0f : 1.0f));
+    fall *= fall;
+    return fall * fall * (dx * gx + dy * gy);
 }
 
+// 2-D simplex noise of one octave (SingleSimplex, FastNoise.cpp:1274-1335): skew the point onto the lattice of
+// unit cells, un-skew the cell origin, and sum the terms of the triangle's three corners -- the origin, the
+// middle corner (one step along the larger of the two offsets), and the far corner (1, 1).
 __device__ float fn_simplex2(const uint8_t* perm, const uint8_t* perm12, uint32_t offset, float x, float y, float F2, float G2, float two_G2)
 {
-    // SingleSimplex (:1274-1335)
-    float t = (x + y) * F2;
-    const int i = fn_fast_floor(x + t), j = fn_fast_floor(y + t);
-    t = (float)(i + j) * G2;
-    const float X0 = (float)i - t, Y0 = (float)j - t;
-    const float x0 = x - X0, y0 = y - Y0;
-    const int i1 = x0 > y0 ? 1 : 0, j1 = x0 > y0 ? 0 : 1;
-    const float x1 = x0 - (float)i1 + G2, y1 = y0 - (float)j1 + G2;
-    const float x2 = x0 - 1.0f + two_G2, y2 = y0 - 1.0f + two_G2;
-    float n0 = 0.0f, n1 = 0.0f, n2 = 0.0f;
-    t = 0.5f - x0 * x0 - y0 * y0;
-    if (!(t < 0)) { t *= t; n0 = t * t * fn_grad2(perm, perm12, offset, i, j, x0, y0); }
-    t = 0.5f - x1 * x1 - y1 * y1;
-    if (!(t < 0)) { t *= t; n1 = t * t * fn_grad2(perm, perm12, offset, i + i1, j + j1, x1, y1); }
-    t = 0.5f - x2 * x2 - y2 * y2;
-    if (!(t < 0)) { t *= t; n2 = t * t * fn_grad2(perm, perm12, offset, i + 1, j + 1, x2, y2); }
-    return 70.0f * (n0 + n1 + n2);
+    const float skew = (x + y) * F2;
+    const int cell_x = fn_fast_floor(x + skew), cell_y = fn_fast_floor(y + skew);
+    const float unskew = (float)(cell_x + cell_y) * G2;
+    const float ox = x - ((float)cell_x - unskew), oy = y - ((float)cell_y - unskew);   // offset from the cell origin
+    const int step_x = ox > oy ? 1 : 0, step_y = 1 - step_x;
+    float sum = fn_corner2(perm, perm12, offset, cell_x, cell_y, ox, oy);
+    sum = sum + fn_corner2(perm, perm12, offset, cell_x + step_x, cell_y + step_y, ox - (float)step_x + G2, oy - (float)step_y + G2);
+    sum = sum + fn_corner2(perm, perm12, offset, cell_x + 1, cell_y + 1, ox - 1.0f + two_G2, oy - 1.0f + two_G2);
+    return 70.0f * sum;
 }
 
 __global__ void k_terrain_heights(NoiseTables tab, uint32_t S, int32_t* __restrict__ height)
@@ -337,13 +369,13 @@ extern "C" int vrc_scene_build_fastnoise_terrain(int32_t seed, uint32_t depth, i
     int32_t *d_h = nullptr, *d_lim = nullptr;
     hipError_t e = hipMalloc((void**)&d_h, (size_t)S * S * 4);
     if (e == hipSuccess) e = hipMalloc((void**)&d_lim, (size_t)S * S * 4);
-    if (e == hipSuccess) {
+    if (e != hipSuccess) rc = vrc::fail(e == hipErrorOutOfMemory ? VRC_ERR_OOM : VRC_ERR_HIP, "vrc_scene_build_fastnoise_terrain: %s", hipGetErrorString(e));
+    else rc = build_on_device(TerrainVox{d_lim, S}, depth, device, cus, out, build_ms, [&]() {
+        // inside the timed region: *build_ms covers noise -> heights -> column limits -> LSVO
         hipLaunchKernelGGL(k_terrain_heights, grid_for((uint64_t)S * S), dim3(256), 0, nullptr, tab, S, d_h);
         hipLaunchKernelGGL(k_terrain_lim, grid_for((uint64_t)S * S), dim3(256), 0, nullptr, d_h, d_lim, S);
-        e = hipGetLastError();
-    }
-    if (e != hipSuccess) rc = vrc::fail(e == hipErrorOutOfMemory ? VRC_ERR_OOM : VRC_ERR_HIP, "vrc_scene_build_fastnoise_terrain: %s", hipGetErrorString(e));
-    else rc = build_on_device(TerrainVox{d_lim, S}, depth, device, cus, out, build_ms);
+        return hipGetLastError();
+    });
     (void)hipFree(d_h);
     (void)hipFree(d_lim);
     return rc;
@@ -361,12 +393,11 @@ extern "C" int vrc_scene_build_terrain(const int32_t* height, uint32_t depth, in
     hipError_t e = hipMalloc((void**)&d_h, (size_t)S * S * 4);
     if (e == hipSuccess) e = hipMalloc((void**)&d_lim, (size_t)S * S * 4);
     if (e == hipSuccess) e = hipMemcpy(d_h, height, (size_t)S * S * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_terrain_lim, grid_for((uint64_t)S * S), dim3(256), 0, nullptr, d_h, d_lim, S);
-        e = hipGetLastError();
-    }
     if (e != hipSuccess) rc = vrc::fail(e == hipErrorOutOfMemory ? VRC_ERR_OOM : VRC_ERR_HIP, "vrc_scene_build_terrain: %s", hipGetErrorString(e));
-    else rc = build_on_device(TerrainVox{d_lim, S}, depth, device, cus, out, build_ms);
+    else rc = build_on_device(TerrainVox{d_lim, S}, depth, device, cus, out, build_ms, [&]() {
+        hipLaunchKernelGGL(k_terrain_lim, grid_for((uint64_t)S * S), dim3(256), 0, nullptr, d_h, d_lim, S);
+        return hipGetLastError();
+    });
     (void)hipFree(d_h);
     (void)hipFree(d_lim);
     return rc;
@@ -384,7 +415,7 @@ extern "C" int vrc_scene_build_volume(const uint8_t* solid, uint32_t depth, int 
     hipError_t e = hipMalloc((void**)&d_solid, S * S * S);
     if (e == hipSuccess) e = hipMemcpy(d_solid, solid, S * S * S, hipMemcpyHostToDevice);
     if (e != hipSuccess) rc = vrc::fail(e == hipErrorOutOfMemory ? VRC_ERR_OOM : VRC_ERR_HIP, "vrc_scene_build_volume: %s", hipGetErrorString(e));
-    else rc = build_on_device(VolumeVox{d_solid, (uint32_t)S}, depth, device, cus, out, build_ms);
+    else rc = build_on_device(VolumeVox{d_solid, (uint32_t)S}, depth, device, cus, out, build_ms, []() { return hipSuccess; });
     (void)hipFree(d_solid);
     return rc;
 }

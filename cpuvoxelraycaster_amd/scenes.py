@@ -5,20 +5,24 @@ import os
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-GOLDEN = os.path.join(ROOT, "tests", "golden")
+DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
 
 
-def load_terrain_heights():
-    """int32 height[x, z] of main.cpp:69 for x, z < 1024 (fixture generated from
-    the reference's vendored FastNoise by tests/tools/make_golden.py)."""
-    return np.load(os.path.join(GOLDEN, "terrain_height_1024.npz"))["height"].astype(np.int32)
+def terrain_heights(size=1024, seed=1337, device=0):
+    """int32 height[x, z] of main.cpp:69 for x, z < size, evaluated on the GPU (vrc_terrain_heights: the reference's
+    FastNoise settings, bit-identical to lib/fastnoise -- pinned by tests/test_gpu_builder.py against a fixture made
+    with the reference's own FastNoise.cpp)."""
+    from . import capi
+    h = np.zeros((size, size), np.int32)
+    capi.check(capi.load().vrc_terrain_heights(seed, size, device, capi.ptr(h)))
+    return h
 
 
 def load_textures():
-    """(top, side) 16x16 RGB tables of res/grass_{top,side}_16x16.bmp."""
-    top = np.fromfile(os.path.join(GOLDEN, "grass_top_16x16.rgb"), np.uint8)
-    side = np.fromfile(os.path.join(GOLDEN, "grass_side_16x16.rgb"), np.uint8)
+    """(top, side) 16x16 RGB tables, top-down rows, as sf::Image::getPixel sees res/grass_{top,side}_16x16.bmp
+    (raycaster.hpp:53-54): 768 bytes each, shipped with the package (data/)."""
+    top = np.fromfile(os.path.join(DATA, "grass_top_16x16.rgb"), np.uint8)
+    side = np.fromfile(os.path.join(DATA, "grass_side_16x16.rgb"), np.uint8)
     return top, side
 
 

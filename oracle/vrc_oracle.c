@@ -674,6 +674,8 @@ typedef struct {
     const uint8_t *tex_top, *tex_side;
     v3 light;
     uint64_t rays, sum_complexity;
+    uint16_t *trace;           /* analysis hook (orc_render_frame_trace): complexity of this pixel's rays, in cast order */
+    uint32_t trace_n;
 } shade_ctx;
 
 static void ctx_cast(shade_ctx *c, v3 o, v3 d, float coef, float bias, orc_hit *out)
@@ -682,6 +684,8 @@ static void ctx_cast(shade_ctx *c, v3 o, v3 d, float coef, float bias, orc_hit *
     orc_cast_ray(c->nodes, c->depth, of, df, coef, bias, out);
     c->rays += 1;
     c->sum_complexity += out->complexity;
+    if (c->trace && c->trace_n < ORC_TRACE_RAYS)
+        c->trace[c->trace_n++] = (uint16_t)(out->complexity < 65535u ? out->complexity : 65535u);
 }
 
 /* camera_controller.hpp:51-54: row-vector * mat3 */
@@ -820,9 +824,11 @@ static int pixel_selected(const orc_frame_params *p, uint32_t x, uint32_t y)
 }
 
 static void render_pixel(shade_ctx *c, const orc_camera *cam, const orc_frame_params *p,
-                         uint32_t x, uint32_t y, uint8_t *image, uint32_t *accum, orc_hit *prim)
+                         uint32_t x, uint32_t y, uint8_t *image, uint32_t *accum, orc_hit *prim, uint16_t *trace)
 {
     const uint32_t W = p->width, H = p->height;
+    c->trace = trace ? trace + ((uint64_t)y * W + x) * ORC_TRACE_RAYS : 0;
+    c->trace_n = 0;
     const float inv_size = 1.0f / (float)(1u << c->depth);     /* main.cpp:82 */
     rng_t rng = { p->rng_mode, p->seed, p->frame_index, y * W + x, 0u };
     /* main.cpp:133,145-146 */
@@ -868,26 +874,35 @@ void orc_render_frame(const orc_lnode *nodes, uint32_t depth,
                       uint8_t *image, uint32_t *accum, orc_hit *prim,
                       orc_frame_stats *stats, int threads)
 {
+    orc_render_frame_trace(nodes, depth, tex_top, tex_side, cam, p, image, accum, prim, stats, threads, 0);
+}
+
+void orc_render_frame_trace(const orc_lnode *nodes, uint32_t depth,
+                            const uint8_t tex_top[768], const uint8_t tex_side[768],
+                            const orc_camera *cam, const orc_frame_params *p,
+                            uint8_t *image, uint32_t *accum, orc_hit *prim,
+                            orc_frame_stats *stats, int threads, uint16_t *trace)
+{
     const uint32_t W = p->width, H = p->height;
     uint64_t rays = 0, sumc = 0, hits = 0;
     if (p->rng_mode == 1 || threads <= 1) {
         /* serial: the reference's own pixel order within its 4x4 tiles is
          * thread-racy; x-outer/y-inner (main.cpp:142-143) over the whole frame here */
         shade_ctx c = { nodes, depth, tex_top, tex_side,
-                        { p->light_position[0], p->light_position[1], p->light_position[2] }, 0, 0 };
+                        { p->light_position[0], p->light_position[1], p->light_position[2] }, 0, 0, 0, 0 };
         for (uint32_t x = 0; x < W; x++)
             for (uint32_t y = 0; y < H; y++)
                 if (pixel_selected(p, x, y))
-                    render_pixel(&c, cam, p, x, y, image, accum, prim);
+                    render_pixel(&c, cam, p, x, y, image, accum, prim, trace);
         rays = c.rays; sumc = c.sum_complexity;
     } else {
 #pragma omp parallel for schedule(dynamic, 4) num_threads(threads) reduction(+ : rays, sumc)
         for (int32_t y = 0; y < (int32_t)H; y++) {
             shade_ctx c = { nodes, depth, tex_top, tex_side,
-                            { p->light_position[0], p->light_position[1], p->light_position[2] }, 0, 0 };
+                            { p->light_position[0], p->light_position[1], p->light_position[2] }, 0, 0, 0, 0 };
             for (uint32_t x = 0; x < W; x++)
                 if (pixel_selected(p, x, (uint32_t)y))
-                    render_pixel(&c, cam, p, x, (uint32_t)y, image, accum, prim);
+                    render_pixel(&c, cam, p, x, (uint32_t)y, image, accum, prim, trace);
             rays += c.rays; sumc += c.sum_complexity;
         }
     }

@@ -145,6 +145,15 @@ void orc_render_frame(const orc_lnode *nodes, uint32_t depth,
                       const orc_camera *cam, const orc_frame_params *p,
                       uint8_t *image, uint32_t *accum, orc_hit *prim,
                       orc_frame_stats *stats, int threads);
+/* Analysis hook (tools/): the same frame, and per pixel the loop-iteration counts of its first ORC_TRACE_RAYS
+ * castRay calls in cast order (primary, shadow..., GI, GI shadow, ...) into trace[pixel * ORC_TRACE_RAYS + k]
+ * (untouched entries stay as the caller set them).  trace == NULL is orc_render_frame. */
+#define ORC_TRACE_RAYS 8
+void orc_render_frame_trace(const orc_lnode *nodes, uint32_t depth,
+                            const uint8_t tex_top[768], const uint8_t tex_side[768],
+                            const orc_camera *cam, const orc_frame_params *p,
+                            uint8_t *image, uint32_t *accum, orc_hit *prim,
+                            orc_frame_stats *stats, int threads, uint16_t *trace);
 /* raycaster.hpp:94-103 / :105-116 */
 void orc_samples_to_image(const uint32_t *accum, uint32_t width, uint32_t height, uint8_t *image);
 

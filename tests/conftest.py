@@ -22,11 +22,11 @@ def built():
 
 @pytest.fixture(scope="session")
 def heights():
-    import cpuvoxelraycaster_amd as vrc
-    return vrc.load_terrain_heights()
+    import oracle_lib
+    return oracle_lib.load_terrain_heights()
 
 
 @pytest.fixture(scope="session")
 def textures():
-    import cpuvoxelraycaster_amd as vrc
-    return vrc.load_textures()
+    import oracle_lib
+    return oracle_lib.load_textures()

@@ -50,6 +50,22 @@ def build_oracle(force=False):
     return LIB_PATH
 
 
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def load_terrain_heights():
+    """int32 height[x, z] of main.cpp:69 for x, z < 1024: fixture generated from the reference's vendored FastNoise
+    (oracle/_ref) by tests/tools/make_golden.py."""
+    return np.load(os.path.join(GOLDEN, "terrain_height_1024.npz"))["height"].astype(np.int32)
+
+
+def load_textures():
+    """(top, side) 16x16 RGB tables decoded from the reference's res/grass_{top,side}_16x16.bmp (tests/golden)."""
+    top = np.fromfile(os.path.join(GOLDEN, "grass_top_16x16.rgb"), np.uint8)
+    side = np.fromfile(os.path.join(GOLDEN, "grass_side_16x16.rgb"), np.uint8)
+    return top, side
+
+
 _lib = None
 
 

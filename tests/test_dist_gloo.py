@@ -32,8 +32,8 @@ def _worker(rank, world, port, W, H, q):
     import cpuvoxelraycaster_amd.dist as vd
     import cpuvoxelraycaster_amd.scenes as scenes
     depth = 7
-    nodes = O.compile_terrain(depth, scenes.load_terrain_heights())
-    top, side = scenes.load_textures()
+    nodes = O.compile_terrain(depth, O.load_terrain_heights())
+    top, side = O.load_textures()
     light = scenes.reference_light(depth)
     cam = O.make_camera(scenes.reference_camera_position(depth), O.make_rotation(0.0, -0.5))
     acc = None

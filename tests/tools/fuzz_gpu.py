@@ -22,7 +22,7 @@ def main():
     import raygen
     L = vrc.capi.load()
     top, side = vrc.load_textures()
-    heights = vrc.load_terrain_heights()
+    heights = O.load_terrain_heights()
     t0 = time.time()
     it = bad = rays_total = frames = 0
     while time.time() - t0 < args.seconds:

@@ -34,7 +34,7 @@ def fnv1a64(b):
 
 
 def main():
-    heights = vrc.load_terrain_heights()
+    heights = O.load_terrain_heights()
     top, side = vrc.load_textures()
     nodes = O.compile_terrain(9, heights)
     org, d = raygen.mixed_rays(4096, seed=2024)

@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import cpuvoxelraycaster_amd as vrc
 import oracle_lib as O
 
-h = vrc.load_terrain_heights()
+h = O.load_terrain_heights()
 print("depth nodes      bytes(MiB)  gpu_kernels_ms  gpu_call_ms  host_builder_s  oracle_setcell+compile_s  GB/s(out)")
 for depth in (7, 8, 9, 10):
     vrc.LSVO.fromTerrain(h, depth)  # warm

@@ -17,7 +17,7 @@ def main():
     import cpuvoxelraycaster_amd as vrc
     import raygen
     depth = 9
-    svo = vrc.LSVO.fromTerrain(vrc.load_terrain_heights(), depth)
+    svo = vrc.LSVO.fromTerrain(vrc.terrain_heights(), depth)
     stream = torch.cuda.current_stream().cuda_stream
     sets = {}
     o, d = raygen.camera_rays(depth, 1920, 1080, -0.5)

@@ -25,7 +25,7 @@ def main():
     import cpuvoxelraycaster_amd as vrc
     cfg = bench.CONFIGS[args.config]
     depth, W, H, spp = cfg["depth"], cfg["width"], cfg["height"], cfg["spp"]
-    nodes = vrc.build_terrain_lsvo(vrc.load_terrain_heights(), depth)
+    nodes = vrc.build_terrain_lsvo(vrc.terrain_heights(), depth)
     svo = vrc.LSVO(nodes, depth, textures=vrc.load_textures())
     rc = vrc.RayCaster(svo, (W, H))
     rc.setLightPosition(vrc.reference_light(depth))
