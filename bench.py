@@ -55,36 +55,109 @@ ROW_BLOCK = 8
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def cpu_baseline(cfg, nodes, textures, cam, light, budget_s=12.0):
-    """The oracle (bit-identical CPU restatement, kind "port") timed on this box's
-    host cores on a bounded sample of the same workload: 1/16-frame row-block
-    shards of the same frame, one sample each, until ~budget_s seconds."""
+KERNEL_SOURCES = ["vrc_kernels.hip", "vrc_walk.h", "vrc_device.h", "vrc_internal.h"]
+
+
+def kernel_source_hash():
+    """Identifies the frame-kernel sources a PMC measurement belongs to (profiles/traffic.json is stamped with it)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "cpuvoxelraycaster_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_record(key):
+    """The rocprofv3 PMC record of this workload from profiles/traffic.json (tools/pmc_roofline.sh +
+    tools/update_traffic.py), or (None, reason) when there is none FOR THE KERNEL SOURCES OF THIS TREE."""
+    prof = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        rec = json.load(open(prof)).get("entries", {}).get(key)
+    except Exception as e:                                       # noqa: BLE001
+        return None, f"profiles/traffic.json unreadable: {e}"
+    if rec is None:
+        return None, f"no PMC record for {key} in profiles/traffic.json"
+    cur = kernel_source_hash()
+    if rec.get("source_hash") != cur:
+        return None, (f"profiles/traffic.json[{key}] was measured on kernel sources {rec.get('source_hash')} (commit "
+                      f"{rec.get('commit')}); this tree's are {cur}: re-run tools/pmc_roofline.sh + tools/update_traffic.py")
+    return rec, None
+
+
+def cpu_baseline(cfg, nodes, textures, cam, light, budget_s=5.0):
+    """The oracle (bit-identical CPU restatement, kind "port") timed on this box's host cores on a bounded sample of
+    the same workload: whole frame-samples (every pixel once: 1/spp of a frame), three ways:
+      4x4x16     the reference's own decomposition: 16 threads, thread t owns area (t % 4, t / 4), x-outer / y-inner
+                 (main.cpp:90-92,139-152), parity build (-O2 -ffp-contract=off)
+      omp-nproc  OpenMP dynamic rows over all usable host cores, parity build -- the headline `value`
+      native     the same source built -O3 -march=native with FMA contraction allowed: NON-parity (its results may
+                 differ from the reference's; it is only timed), omp-nproc decomposition
+    each for ~budget_s seconds and at least one whole frame-sample."""
+    import ctypes as C
+    import subprocess
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
-    threads = max(1, min(os.cpu_count() or 1, 64))
+    try:
+        usable = len(os.sched_getaffinity(0))                    # the cores this process may run on (cgroup / affinity)
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    threads = max(1, usable)
     top, side = textures
     ocam = O.make_camera(tuple(cam.position), tuple(cam.rot), cam.fov, cam.aperture, cam.focal_length)
     W, H = cfg["width"], cfg["height"]
-    rays = 0
-    done = 0
-    shards = 16
-    t0 = time.perf_counter()
-    s = 0
-    while time.perf_counter() - t0 < budget_s:
-        # sample s of the frame, shard by shard (later passes repeat the workload with the next sample indices)
-        for k in range(shards):
-            p = O.make_params(W, H, light, use_gi=cfg["use_gi"], use_samples=1, shadow_samples=1, frame_index=s,
-                              gi_bounces=cfg.get("gi_bounces", 1), row_block=ROW_BLOCK, shard_index=k, shard_count=shards)
-            _, _, _, st = O.render_frame(nodes, cfg["depth"], top, side, ocam, p, threads=threads)
+    L = O.lib()
+    sig = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(O.Camera), C.POINTER(O.FrameParams),
+           C.c_void_p, C.c_void_p]
+    L.orc_render_frame_areas16.argtypes = sig + [C.POINTER(O.FrameStats)]
+    native = None
+    try:
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "native"], stdout=subprocess.DEVNULL,
+                              stderr=subprocess.DEVNULL)
+        native = C.CDLL(os.path.join(ROOT, "oracle", "_native", "libvrc_oracle_native.so"))
+        native.orc_render_frame.argtypes = sig + [C.c_void_p, C.POINTER(O.FrameStats), C.c_int]
+    except Exception:                                            # noqa: BLE001  (no compiler: the variant is left out)
+        native = None
+    import numpy as np
+    img = np.zeros((H, W, 4), np.uint8)
+    acc = np.zeros((H, W, 4), np.uint32)
+
+    def run(kind):
+        rays = n = 0
+        t0 = time.perf_counter()
+        while n == 0 or time.perf_counter() - t0 < budget_s:
+            p = O.make_params(W, H, light, use_gi=cfg["use_gi"], use_samples=1, shadow_samples=1, frame_index=n,
+                              gi_bounces=cfg.get("gi_bounces", 1))
+            st = O.FrameStats()
+            args = (O._ptr(nodes), cfg["depth"], O._ptr(top), O._ptr(side), C.byref(ocam), C.byref(p), O._ptr(img), O._ptr(acc))
+            if kind == "areas16":
+                L.orc_render_frame_areas16(*args, C.byref(st))
+            elif kind == "native":
+                native.orc_render_frame(*args, None, C.byref(st), threads)
+            else:
+                L.orc_render_frame(*args, None, C.byref(st), threads)
             rays += st.rays
-            done += 1
-            if time.perf_counter() - t0 > budget_s:
-                break
-        s += 1
-    dt = time.perf_counter() - t0
-    return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": f"{done} 1/{shards}-frame row-block shards (one sample each; a frame of this workload is "
-                      f"{shards * cfg['spp']} of them), {rays} rays in {dt:.1f} s, oracle built -O2 -ffp-contract=off, OpenMP {threads} threads"}
+            n += 1
+        dt = time.perf_counter() - t0
+        return rays, n, dt
+
+    out = []
+    r, n, dt = run("areas16")
+    out.append({"decomp": "4x4x16", "threads": 16, "flags": "-O2 -ffp-contract=off", "parity": True,
+                "value": round(r / dt / 1e6, 3), "frame_samples": n, "seconds": round(dt, 2)})
+    r, n, dt = run("omp")
+    head = {"decomp": "omp-nproc", "threads": threads, "flags": "-O2 -ffp-contract=off", "parity": True,
+            "value": round(r / dt / 1e6, 3), "frame_samples": n, "seconds": round(dt, 2)}
+    out.append(head)
+    if native is not None:
+        r2, n2, dt2 = run("native")
+        out.append({"decomp": "omp-nproc", "threads": threads, "flags": "-O3 -march=native (FMA contraction on)",
+                    "parity": False, "value": round(r2 / dt2 / 1e6, 3), "frame_samples": n2, "seconds": round(dt2, 2)})
+    return {"value": head["value"], "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"{n} whole frame-samples of this workload ({W}x{H}, every pixel once; a frame is {cfg['spp']} of them), "
+                      f"{r} rays in {dt:.1f} s, oracle built -O2 -ffp-contract=off, OpenMP dynamic rows on {threads} threads "
+                      f"(os.cpu_count() = {os.cpu_count()}, usable = {usable})",
+            "variants": out}
 
 
 def main():
@@ -98,6 +171,11 @@ def main():
     ap.add_argument("--inflight", type=int, default=0,
                     help="frames in flight per GPU (renderers / streams used round-robin); 1 = one stream, each frame starts "
                          "when the previous one has ended; 0 = automatic: 1 on one GPU, 2 on several")
+    ap.add_argument("--gather", default="all", choices=["all", "root"],
+                    help="N > 1: how the RGBA8 row-block shards meet: 'all' = RCCL all-gather (every rank ends up with the "
+                         "frame), 'root' = RCCL gather to rank 0, the presenting rank (north_star / SURVEY 8e: 1/N of the "
+                         "bytes on the wire)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra measurements (2-bounce extension)")
     ap.add_argument("--tuning", default="", help="blocks_per_cu,refill_threshold,chunk")
     ap.add_argument("--kernel", type=int, default=2,
                     help="frame kernel: 2 stage-synchronous per tile (default), 0 tile-phased with LDS job pool, 1 persistent mixed-stage")
@@ -109,6 +187,7 @@ def main():
 
     import __graft_entry__ as g
     import cpuvoxelraycaster_amd as vrc
+    import cpuvoxelraycaster_amd.dist as vdist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -116,6 +195,7 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+        sys.exit(f"bench.py --gpus {args.gpus} launched with WORLD_SIZE={world}: they must agree")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     # one process per GPU; VRC_DIST_BACKEND=gloo (+ ranks sharing a GPU) exists only to exercise the
@@ -136,6 +216,8 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
+        # the process group must span exactly the ranks the driver asked for
+        assert dist.get_world_size() == max(args.gpus, 1) == world, (dist.get_world_size(), args.gpus, world)
     # the in-tree libraries travel with the snapshot; if they are missing or stale, ONE process per node builds
     # (N ranks writing the same .so at once would corrupt it) and the others wait
     if dist_on:
@@ -153,7 +235,11 @@ def main():
     textures = vrc.load_textures()
     # main.cpp:59-88 on the GPU: FastNoise heights -> LSVO, straight into HBM (csrc/vrc_build_gpu.hip);
     # the LNode[] is resident from here on
+    # (a first, untimed build pays the one-time costs of the process: code-object load, first allocations)
+    vrc.LSVO.fromFastNoiseTerrain(min(depth, 7), seed=1337, device=local_rank).close()
+    t_build = time.perf_counter()
     svo = vrc.LSVO.fromFastNoiseTerrain(depth, seed=1337, device=local_rank, textures=textures)
+    build_call_ms = (time.perf_counter() - t_build) * 1e3        # whole call: allocations + noise + build + texture upload
     light = vrc.reference_light(depth)
     cam = vrc.reference_camera(depth, pitch=args.pitch, aperture=cfg["aperture"],
                                focal_length=(60.0 * (1 << depth) / 512.0 if cfg["aperture"] else 1.0))
@@ -195,10 +281,12 @@ def main():
         work = state["pending"][slot]
         if work != "sync":
             work.wait()                                        # current stream waits for the collective
+        state["pending"][slot] = None
+        if args.gather == "root" and rank != 0:
+            return                                             # only the presenting rank composes the frame
         vrc.capi.check(L.vrc_unpack_shards(vrc.capi.ptr(gathered[slot].data_ptr()), W, H, ROW_BLOCK, world,
                                            vrc.capi.ptr(full[slot].data_ptr()),
                                            vrc.capi.ptr(torch.cuda.current_stream().cuda_stream)))
-        state["pending"][slot] = None
 
     def step(timed):
         # one frame = render (spp samples per pixel into the accumulators) + one pass that resolves this rank's
@@ -223,8 +311,10 @@ def main():
             if dist_on:
                 rc.resolveShard(ROW_BLOCK, rank, world, mine[slot].data_ptr(), reset=True, stream=stream)
                 if backend == "nccl":
-                    # RCCL over xGMI: RGBA8 row-block shards; enqueued behind the resolve, runs beside the next render
-                    state["pending"][slot] = dist.all_gather_into_tensor(gathered[slot], mine[slot], async_op=True)
+                    # RCCL over xGMI: RGBA8 row-block shards; enqueued behind the resolve, runs beside the next render.
+                    # --gather all: all-gather; --gather root: rank 0 receives every shard straight into its place of
+                    # the [shard][slot] buffer (one direct hop per peer), the other ranks only send
+                    state["pending"][slot] = vdist.exchange_shards(mine[slot], gathered[slot], world, rank, args.gather, async_op=True)
                 else:
                     ts.synchronize()
                     parts = [torch.empty_like(mine[slot]) for _ in range(world)]
@@ -298,22 +388,66 @@ def main():
         torch.cuda.synchronize()
         verified = bool(np.array_equal(full[state["last_slot"]].cpu().numpy().reshape(H, W, 4), ref.readImage(stream)))
 
+    # untimed extra, N = 1 only: BASELINE config 3's text says "GI 2 bounces"; the reference has ONE indirect bounce
+    # (RayContext::gi_bounce is never read), which is what `value` measures -- the 2-bounce EXTENSION
+    # (recursive getGlobalIllumination at the GI hit, defined by the oracle) is reported beside it
+    extras = {}
+    if rank == 0 and world == 1 and not dist_on and not args.no_extras and args.config == "c3":
+        rc2 = make_renderer()
+        rc2.gi_bounces = 2
+        ts = tstreams[0]
+        n2 = max(10, min(args.steps, 50))
+        with torch.cuda.stream(ts):
+            for i in range(3):
+                rc2.frame_index = i * spp
+                rc2.renderFrame(cam, spp=spp, stream=ts.cuda_stream)
+                rc2.resolveShard(reset=True, stream=ts.cuda_stream)
+            torch.cuda.synchronize()
+            rc2.stats(reset=True, stream=ts.cuda_stream)
+            t2 = time.perf_counter()
+            for i in range(n2):
+                rc2.frame_index = i * spp
+                rc2.renderFrame(cam, spp=spp, stream=ts.cuda_stream)
+                rc2.resolveShard(reset=True, stream=ts.cuda_stream)
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t2
+        st2 = rc2.stats(stream=ts.cuda_stream)
+        extras["gi_2_bounce_extension"] = {
+            "value": round(st2.rays / dt2 / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(dt2 / n2 * 1e3, 4), "steps": n2,
+            "rays_per_frame": st2.rays // n2, "loop_iterations_per_frame": st2.sum_complexity // n2,
+            "note": "extension without reference behaviour: bounce 2 = getGlobalIllumination applied again at the GI hit "
+                    "(oracle/vrc_oracle.c global_illumination, level 1); same frame, same kernel, measured right after the timed region"}
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        # roofline of the dominant kernel (k_render), this rank's launches:
+        # roofline of the dominant kernel (k_render_sync), this rank's launches:
         # algorithmic bytes per launch = 8 B per traversal-loop iteration (one LNode, lsvo.hpp:74)
         # + one 32 B accumulator read-modify-write per pixel of the launch (raycaster.hpp:87-90)
         my_steps_per_launch = st.sum_complexity / args.steps
         my_pixels_per_launch = st.pixels / args.steps / spp
         alg_bytes = 8.0 * my_steps_per_launch + 32.0 * my_pixels_per_launch
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-        traffic = None
-        prof = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(prof):
-            try:
-                traffic = json.load(open(prof)).get(f"{args.config}_n{world}")
-            except Exception:
-                traffic = None
+        # measured HBM / fabric bytes and instruction-issue numbers of the same workload come from the rocprofv3 PMC
+        # passes recorded in profiles/traffic.json -- only when that record was taken on THIS tree's kernel sources
+        rec, why = pmc_record(f"{args.config}_n{world}") if args.kernel == 2 else (None, "PMC record exists for k_render_sync only")
+        traffic = rec["traffic_bytes"] if rec else None
+        roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
+                "kernel": {0: "k_render_tile", 1: "k_render", 2: "k_render_sync"}[args.kernel], "kernel_ms": round(kernel_ms, 4),
+                "kernel_ms_max_rank": round(kernel_ms_max, 4), "algorithmic_bytes_per_launch": int(alg_bytes),
+                "achieved_is": "ALGORITHMIC bytes (SURVEY 8d: 8 B per walk-loop iteration + 32 B per pixel) / kernel time -- nominal by "
+                               "construction: the tree is L1/L2-resident, see traffic_frac_of_peak, and the binding limit is VALU "
+                               "instruction issue, see issue"}
+        if rec:
+            roof["traffic_frac_of_peak"] = round(traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5)
+            roof["traffic_detail"] = {k: rec[k] for k in ("fetch_bytes", "write_bytes", "profile", "commit", "profiled_kernel_ms") if k in rec}
+            roof["issue"] = {"valu_wave_instr_per_launch": rec.get("valu_wave_instr"),
+                             "lane_utilisation": rec.get("lane_utilisation"),
+                             "simd_cycles_per_valu_instr": rec.get("simd_cycles_per_valu_instr"),
+                             "note": "rocprofv3 PMC, per launch: SQ_INSTS_VALU; SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); "
+                                     "GRBM_GUI_ACTIVE / 8 x 1024 SIMDs / SQ_INSTS_VALU"}
+        else:
+            roof["traffic_note"] = why
         out = {
             "metric": "Mrays/s + ms/frame, 512^3 LSVO @1920x1080 4spp GI, 1/2/4/8 GPU",
             "value": round(rays / elapsed / 1e6, 2),
@@ -328,14 +462,15 @@ def main():
             "config": {"workload": cfg["label"], "rays_per_frame": rays // args.steps,
                        "loop_iterations_per_frame": steps_sum // args.steps,
                        "camera_pitch": args.pitch, "lsvo_nodes": svo.n_nodes,
-                       "lsvo_gpu_build_ms": round(svo.build_ms, 3), "frames_in_flight": F, "sharding": f"{ROW_BLOCK}-row blocks round-robin over {world} GPU(s)"
-                       + (", RCCL all-gather of RGBA8 shards" if dist_on else ""),
+                       "lsvo_gpu_build_ms": round(svo.build_ms, 3), "lsvo_gpu_build_call_ms": round(build_call_ms, 3),
+                       "frames_in_flight": F, "sharding": f"{ROW_BLOCK}-row blocks round-robin over {world} GPU(s)"
+                       + (f", RCCL {'gather to rank 0' if args.gather == 'root' else 'all-gather'} of RGBA8 shards" if dist_on else ""),
+                       "ranks_in_process_group": (dist.get_world_size() if dist_on else 1),
                        "gathered_frame_equals_unsharded": verified},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
-                         "kernel": {0: "k_render_tile", 1: "k_render", 2: "k_render_sync"}[args.kernel], "kernel_ms": round(kernel_ms, 4), "kernel_ms_max_rank": round(kernel_ms_max, 4),
-                         "algorithmic_bytes_per_launch": int(alg_bytes)},
+            "roofline": roof,
         }
+        if extras:
+            out["extra"] = extras
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, svo.downloadNodes(), textures, cam, light)
     if dist_on:

@@ -3,9 +3,9 @@ johnBuffer/CpuVoxelRaycaster as hand-written HIP kernels behind a C ABI
 (include/vrc.h).  See DESIGN.md."""
 from . import capi
 from .capi import VrcError, HIT_DTYPE, LNODE_DTYPE, build_terrain_lsvo, build_volume_lsvo, make_rotation
-from .raycaster import LSVO, Grid3D, RayCaster, make_camera
+from .raycaster import LSVO, Grid3D, RayCaster, Presenter, make_camera
 from .scenes import terrain_heights, load_textures, reference_camera, reference_camera_position, reference_light
 
 __all__ = ["capi", "VrcError", "HIT_DTYPE", "LNODE_DTYPE", "build_terrain_lsvo", "build_volume_lsvo",
-           "make_rotation", "LSVO", "Grid3D", "RayCaster", "make_camera", "terrain_heights",
+           "make_rotation", "LSVO", "Grid3D", "RayCaster", "Presenter", "make_camera", "terrain_heights",
            "load_textures", "reference_camera", "reference_camera_position", "reference_light"]

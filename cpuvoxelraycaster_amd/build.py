@@ -5,7 +5,7 @@ import subprocess
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libvrc_hip.so")
-SOURCES = ["vrc_kernels.hip", "vrc_build_gpu.hip", "vrc_api.cpp", "vrc_builder.cpp"]
+SOURCES = ["vrc_kernels.hip", "vrc_build_gpu.hip", "vrc_present.hip", "vrc_api.cpp", "vrc_builder.cpp"]
 HEADERS = ["vrc_device.h", "vrc_walk.h", "vrc_internal.h", os.path.join("..", "..", "include", "vrc.h")]
 
 # -ffp-contract=off: hipcc fuses a*b+c into v_fma_f32 by default, which changes

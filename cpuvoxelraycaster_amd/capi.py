@@ -88,7 +88,18 @@ SYMBOLS = {
     "vrc_make_rotation": (None, [_f32, _f32, _vp]),
     "vrc_set_tuning": (_int, [_u32, _u32, _u32]),
     "vrc_set_kernel": (_int, [_u32]),
+    "vrc_presenter_create": (_int, [_int, _u32, _u32, _u32, _u32, C.POINTER(_vp)]),
+    "vrc_presenter_destroy": (_int, [_vp]),
+    "vrc_present": (_int, [_vp, _vp, _f32, _u32, _vp]),
+    "vrc_present_image": (_int, [_vp, _vp, _f32, _u32, _vp]),
+    "vrc_presenter_clear": (_int, [_vp, _vp]),
+    "vrc_presenter_window_ptr": (_vp, [_vp]),
+    "vrc_presenter_denoised_ptr": (_vp, [_vp]),
+    "vrc_presenter_read": (_int, [_vp, _vp, _vp, _vp]),
     "vrc_set_sample_chunk": (_int, [_u32]),
+    "vrc_renderer_set_tuning": (_int, [_vp, _u32, _u32, _u32]),
+    "vrc_renderer_set_kernel": (_int, [_vp, _u32]),
+    "vrc_renderer_set_sample_chunk": (_int, [_vp, _u32]),
 }
 
 _lib = None

@@ -9,6 +9,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <new>
 
 #include "../../include/vrc.h"
 #include <vector>
@@ -36,6 +38,9 @@ namespace {
         if (e_ != hipSuccess) return fail(VRC_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
+// Scheduling knobs of the frame kernels.  Every renderer carries its own copy (two renderers may use different
+// kernels, from different threads); the process-wide defaults below only seed new renderers and are read and written
+// under g_tuning_mu.
 struct Tuning {
     uint32_t blocks_per_cu = 4;
     uint32_t refill_threshold = 32;
@@ -44,7 +49,36 @@ struct Tuning {
     bool blocks_per_cu_set = false;
     uint32_t sample_chunk = 0;   // 0 = automatic
     uint32_t tail_units_per_wave = 5;   // automatic chunking: units of half the chunk for the last tiles (0 = off)
-} g_tuning;
+};
+Tuning g_tuning;
+std::mutex g_tuning_mu;
+
+constexpr uint32_t VRC_MAX_SPP = 65536;          // per call; the u32 accumulators hold 255 * 16.8 M samples in total
+constexpr uint32_t VRC_MAX_QUEUE_CHUNK = 1u << 20;
+
+int apply_sample_chunk(Tuning& t, uint32_t samples_per_unit)
+{
+    // values above 0xffff0000 set the tail policy of the automatic mode instead (experiments): low 16 bits = units per wave
+    if (samples_per_unit >= 0xffff0000u) { t.tail_units_per_wave = samples_per_unit & 0xffffu; return VRC_OK; }
+    if (samples_per_unit > VRC_MAX_SPP) return vrc::fail(VRC_ERR_INVALID, "sample chunk %u > %u", samples_per_unit, VRC_MAX_SPP);
+    t.sample_chunk = samples_per_unit;
+    return VRC_OK;
+}
+int apply_kernel(Tuning& t, uint32_t kernel)
+{
+    if (kernel > VRC_KERNEL_SYNC) return vrc::fail(VRC_ERR_INVALID, "unknown frame kernel %u", kernel);
+    t.kernel = kernel;
+    return VRC_OK;
+}
+int apply_tuning(Tuning& t, uint32_t blocks_per_cu, uint32_t refill_threshold, uint32_t chunk)
+{
+    if (blocks_per_cu > 8 || refill_threshold > 64 || chunk > VRC_MAX_QUEUE_CHUNK) return vrc::fail(VRC_ERR_INVALID, "tuning out of range");
+    t.blocks_per_cu = blocks_per_cu ? blocks_per_cu : 4;
+    t.blocks_per_cu_set = blocks_per_cu != 0;
+    t.refill_threshold = refill_threshold ? refill_threshold : 32;
+    t.chunk = chunk ? chunk : 64;
+    return VRC_OK;
+}
 
 }  // namespace
 
@@ -55,14 +89,15 @@ struct vrc_grid {
 };
 
 struct vrc_renderer {
-    const vrc_scene* scene;
-    int device;
-    uint32_t width, height;
-    void* d_image;  // RGBA8
-    void* d_accum;  // 4 x u32 per pixel
-    void* d_stats;  // VRC_STATS_BYTES of counter slots, then VRC_QUEUE_BYTES of work-queue heads
-    vrc_hit* d_prim;
-    bool queue_clean;   // the heads were zeroed by vrc_resolve_shard(reset) after the last frame launch
+    const vrc_scene* scene = nullptr;   // must outlive every vrc_render_frame call; the other calls only need r->device
+    int device = 0;
+    uint32_t width = 0, height = 0;
+    void* d_image = nullptr;  // RGBA8
+    void* d_accum = nullptr;  // 4 x u32 per pixel
+    void* d_stats = nullptr;  // VRC_STATS_BYTES of counter slots, then VRC_QUEUE_BYTES of work-queue heads
+    vrc_hit* d_prim = nullptr;
+    bool queue_clean = false;   // the heads were zeroed by vrc_resolve_shard(reset) after the last frame launch
+    Tuning tuning;      // snapshot of the process defaults at creation; vrc_renderer_set_* change it
 };
 
 extern "C" const char* vrc_last_error(void) { return g_err; }
@@ -96,27 +131,33 @@ using vrc::require_device;
 
 extern "C" int vrc_set_sample_chunk(uint32_t samples_per_unit)
 {
-    // values above 0xffff0000 set the tail policy of the automatic mode instead (experiments): low 16 bits = units per wave
-    if (samples_per_unit >= 0xffff0000u) { g_tuning.tail_units_per_wave = samples_per_unit & 0xffffu; return VRC_OK; }
-    g_tuning.sample_chunk = samples_per_unit;
-    return VRC_OK;
+    std::lock_guard<std::mutex> lk(g_tuning_mu);
+    return apply_sample_chunk(g_tuning, samples_per_unit);
 }
-
 extern "C" int vrc_set_kernel(uint32_t kernel)
 {
-    if (kernel > VRC_KERNEL_SYNC) return fail(VRC_ERR_INVALID, "unknown frame kernel %u", kernel);
-    g_tuning.kernel = kernel;
-    return VRC_OK;
+    std::lock_guard<std::mutex> lk(g_tuning_mu);
+    return apply_kernel(g_tuning, kernel);
 }
-
 extern "C" int vrc_set_tuning(uint32_t blocks_per_cu, uint32_t refill_threshold, uint32_t chunk)
 {
-    if (blocks_per_cu > 8 || refill_threshold > 64) return fail(VRC_ERR_INVALID, "tuning out of range");
-    g_tuning.blocks_per_cu = blocks_per_cu ? blocks_per_cu : 4;
-    g_tuning.blocks_per_cu_set = blocks_per_cu != 0;
-    g_tuning.refill_threshold = refill_threshold ? refill_threshold : 32;
-    g_tuning.chunk = chunk ? chunk : 64;
-    return VRC_OK;
+    std::lock_guard<std::mutex> lk(g_tuning_mu);
+    return apply_tuning(g_tuning, blocks_per_cu, refill_threshold, chunk);
+}
+extern "C" int vrc_renderer_set_sample_chunk(vrc_renderer* r, uint32_t samples_per_unit)
+{
+    if (!r) return fail(VRC_ERR_INVALID, "null renderer");
+    return apply_sample_chunk(r->tuning, samples_per_unit);
+}
+extern "C" int vrc_renderer_set_kernel(vrc_renderer* r, uint32_t kernel)
+{
+    if (!r) return fail(VRC_ERR_INVALID, "null renderer");
+    return apply_kernel(r->tuning, kernel);
+}
+extern "C" int vrc_renderer_set_tuning(vrc_renderer* r, uint32_t blocks_per_cu, uint32_t refill_threshold, uint32_t chunk)
+{
+    if (!r) return fail(VRC_ERR_INVALID, "null renderer");
+    return apply_tuning(r->tuning, blocks_per_cu, refill_threshold, chunk);
 }
 
 // ---------------------------------------------------------------------------
@@ -131,24 +172,49 @@ extern "C" int vrc_scene_create(const vrc_lnode* lnodes, uint64_t n_nodes, uint3
     int cus = 0;
     int rc = require_device(device, &cus);
     if (rc) return rc;
-    vrc_scene* s = (vrc_scene*)calloc(1, sizeof(vrc_scene));
+    vrc_scene* s = new (std::nothrow) vrc_scene();
     if (!s) return fail(VRC_ERR_OOM, "out of host memory");
     s->device = device; s->cu_count = cus; s->n_nodes = n_nodes; s->depth = depth;
+    uint8_t* d_level = nullptr;      // n_nodes bytes of level marks, then one u32 of flags (4-byte aligned)
+    const uint64_t flags_off = (n_nodes + 3ull) & ~3ull;
+    uint32_t flags = 0;
     hipError_t e = hipMalloc(&s->d_nodes, n_nodes * sizeof(vrc_lnode));
     if (e == hipSuccess) e = hipMalloc(&s->d_tex, 1536);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_level, flags_off + 4);
     if (e == hipSuccess) e = hipMemcpy(s->d_nodes, lnodes, n_nodes * sizeof(vrc_lnode), hipMemcpyHostToDevice);
     // stray leaf bits (leaf without child: never read by the walk) are cleared in the device copy, see k_sanitize_nodes
     if (e == hipSuccess) e = vrc::launch_sanitize_nodes(s->d_nodes, n_nodes, nullptr);
-    if (e == hipSuccess) e = hipDeviceSynchronize();
+    // The walk indexes nodes[parent + child_offset + slot] and its LDS stack by level without bounds checks (and drops
+    // lsvo.hpp:72's lower loop bound on the strength of the tree being `depth` levels deep): verify both here, once.
+    if (e == hipSuccess) e = hipMemsetAsync(d_level + flags_off, 0, 4, nullptr);
+    if (e == hipSuccess) e = vrc::launch_validate_nodes(s->d_nodes, n_nodes, depth, d_level, (uint32_t*)(d_level + flags_off), nullptr);
+    if (e == hipSuccess) e = hipMemcpy(&flags, d_level + flags_off, 4, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemset(s->d_tex, 0xff, 1536);  // sf::Color::White until textures are set
+    if (d_level) (void)hipFree(d_level);
     if (e != hipSuccess) {
-        if (s->d_nodes) (void)hipFree(s->d_nodes);
-        if (s->d_tex) (void)hipFree(s->d_tex);
-        free(s);
+        vrc::scene_free(s);
         return fail(e == hipErrorOutOfMemory ? VRC_ERR_OOM : VRC_ERR_HIP, "vrc_scene_create: %s", hipGetErrorString(e));
+    }
+    if (flags) {
+        vrc::scene_free(s);
+        return fail(VRC_ERR_INVALID, "vrc_scene_create: malformed LNode array:%s%s%s",
+                    (flags & 1u) ? " a child block reaches past the end of the array;" : "",
+                    (flags & 2u) ? " a non-leaf child below the unit-voxel level (tree deeper than `depth`);" : "",
+                    (flags & 4u) ? " a node is reachable at two different levels;" : "");
     }
     *out = s;
     return VRC_OK;
+}
+
+void vrc::scene_free(vrc_scene* s)
+{
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    if (s->stage_stream) { (void)hipStreamSynchronize(s->stage_stream); (void)hipStreamDestroy(s->stage_stream); }
+    if (s->h_stage) (void)hipHostFree(s->h_stage);
+    if (s->d_nodes) (void)hipFree(s->d_nodes);
+    if (s->d_tex) (void)hipFree(s->d_tex);
+    delete s;
 }
 
 extern "C" int vrc_scene_set_textures(vrc_scene* s, const uint8_t top_rgb[768], const uint8_t side_rgb[768])
@@ -162,11 +228,7 @@ extern "C" int vrc_scene_set_textures(vrc_scene* s, const uint8_t top_rgb[768], 
 
 extern "C" int vrc_scene_destroy(vrc_scene* s)
 {
-    if (!s) return VRC_OK;
-    (void)hipSetDevice(s->device);
-    (void)hipFree(s->d_nodes);
-    (void)hipFree(s->d_tex);
-    free(s);
+    vrc::scene_free(s);
     return VRC_OK;
 }
 
@@ -184,13 +246,18 @@ template <class Launch>
 int staged_cast(uint64_t n, const float* org, const float* dir, const float* coef, const float* bias, vrc_hit* out,
                 hipStream_t st, Launch launch)
 {
+    // one allocation: hits (48 B, 16-byte aligned records first) | origins | directions | coef | bias
     float *d_org = nullptr, *d_dir = nullptr, *d_coef = nullptr, *d_bias = nullptr;
     vrc_hit* d_out = nullptr;
-    hipError_t e = hipMalloc((void**)&d_org, n * 12);
-    if (e == hipSuccess) e = hipMalloc((void**)&d_dir, n * 12);
-    if (e == hipSuccess && coef) e = hipMalloc((void**)&d_coef, n * 4);
-    if (e == hipSuccess && bias) e = hipMalloc((void**)&d_bias, n * 4);
-    if (e == hipSuccess) e = hipMalloc((void**)&d_out, n * sizeof(vrc_hit));
+    uint8_t* arena = nullptr;
+    hipError_t e = hipMalloc((void**)&arena, n * (sizeof(vrc_hit) + 12 + 12 + 4 + 4));
+    if (e == hipSuccess) {
+        d_out = (vrc_hit*)arena;
+        d_org = (float*)(arena + n * sizeof(vrc_hit));
+        d_dir = d_org + 3 * n;
+        if (coef) d_coef = d_dir + 3 * n;
+        if (bias) d_bias = d_dir + 4 * n;
+    }
     if (e == hipSuccess) e = hipMemcpyAsync(d_org, org, n * 12, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(d_dir, dir, n * 12, hipMemcpyHostToDevice, st);
     if (e == hipSuccess && coef) e = hipMemcpyAsync(d_coef, coef, n * 4, hipMemcpyHostToDevice, st);
@@ -198,7 +265,7 @@ int staged_cast(uint64_t n, const float* org, const float* dir, const float* coe
     if (e == hipSuccess) e = launch(d_org, d_dir, d_coef, d_bias, d_out);
     if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, n * sizeof(vrc_hit), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    (void)hipFree(d_org); (void)hipFree(d_dir); (void)hipFree(d_coef); (void)hipFree(d_bias); (void)hipFree(d_out);
+    (void)hipFree(arena);
     if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? VRC_ERR_OOM : VRC_ERR_HIP, "cast_rays: %s", hipGetErrorString(e));
     return VRC_OK;
 }
@@ -225,10 +292,35 @@ extern "C" int vrc_cast_rays(const vrc_scene* s, uint64_t n, const float* org_xy
                        });
 }
 
-extern "C" int vrc_cast_ray(const vrc_scene* s, const float org[3], const float dir[3], float ray_size_coef,
+// Camera::getClosestPoint (camera_controller.hpp:56-60, once per frame, main.cpp:115): the ray goes through the scene's
+// pinned slot -- the kernel reads it from host memory and writes the HitPoint back there; the call is a 32-byte store,
+// one launch on the scene's own stream, a wait for that stream and a 48-byte load.
+extern "C" int vrc_cast_ray(const vrc_scene* cs, const float org[3], const float dir[3], float ray_size_coef,
                             float ray_size_bias, vrc_hit* out)
 {
-    return vrc_cast_rays(s, 1, org, dir, &ray_size_coef, &ray_size_bias, out, VRC_MEM_HOST, nullptr);
+    if (!cs || !org || !dir || !out) return fail(VRC_ERR_INVALID, "vrc_cast_ray: null argument");
+    vrc_scene* s = const_cast<vrc_scene*>(cs);
+    HIP_TRY(hipSetDevice(s->device));
+    std::lock_guard<std::mutex> lk(s->stage_mu);
+    if (!s->h_stage) {
+        void* p = nullptr;
+        HIP_TRY(hipHostMalloc(&p, 128, hipHostMallocMapped));
+        hipStream_t st = nullptr;
+        hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+        if (e != hipSuccess) { (void)hipHostFree(p); return fail(VRC_ERR_HIP, "vrc_cast_ray: %s", hipGetErrorString(e)); }
+        s->h_stage = p; s->stage_stream = st;
+    }
+    float* in = (float*)s->h_stage;                       // org[3] dir[3] coef bias | (64) vrc_hit
+    vrc_hit* res = (vrc_hit*)((uint8_t*)s->h_stage + 64);
+    in[0] = org[0]; in[1] = org[1]; in[2] = org[2]; in[3] = dir[0]; in[4] = dir[1]; in[5] = dir[2];
+    in[6] = ray_size_coef; in[7] = ray_size_bias;
+    void* dev = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&dev, s->h_stage, 0));
+    float* din = (float*)dev;
+    HIP_TRY(vrc::launch_cast_rays(s->d_nodes, (int)s->depth, 1, din, din + 3, din + 6, din + 7, (vrc_hit*)((uint8_t*)dev + 64), s->stage_stream));
+    HIP_TRY(hipStreamSynchronize(s->stage_stream));
+    *out = *res;
+    return VRC_OK;
 }
 
 // ---------------------------------------------------------------------------
@@ -292,9 +384,10 @@ extern "C" int vrc_renderer_create(const vrc_scene* s, uint32_t width, uint32_t 
     if (!s || !out || width == 0 || height == 0) return fail(VRC_ERR_INVALID, "vrc_renderer_create: bad argument");
     if ((uint64_t)width * height > 0x7fffffffull) return fail(VRC_ERR_INVALID, "vrc_renderer_create: frame too large");
     HIP_TRY(hipSetDevice(s->device));
-    vrc_renderer* r = (vrc_renderer*)calloc(1, sizeof(vrc_renderer));
+    vrc_renderer* r = new (std::nothrow) vrc_renderer();
     if (!r) return fail(VRC_ERR_OOM, "out of host memory");
     r->scene = s; r->device = s->device; r->width = width; r->height = height;
+    { std::lock_guard<std::mutex> lk(g_tuning_mu); r->tuning = g_tuning; }
     const uint64_t n = (uint64_t)width * height;
     hipError_t e = hipMalloc(&r->d_image, n * 4);
     if (e == hipSuccess) e = hipMalloc(&r->d_accum, n * 16);
@@ -307,7 +400,7 @@ extern "C" int vrc_renderer_create(const vrc_scene* s, uint32_t width, uint32_t 
         if (r->d_image) (void)hipFree(r->d_image);
         if (r->d_accum) (void)hipFree(r->d_accum);
         if (r->d_stats) (void)hipFree(r->d_stats);
-        free(r);
+        delete r;
         return fail(e == hipErrorOutOfMemory ? VRC_ERR_OOM : VRC_ERR_HIP, "vrc_renderer_create: %s", hipGetErrorString(e));
     }
     *out = r;
@@ -321,8 +414,13 @@ extern "C" int vrc_renderer_destroy(vrc_renderer* r)
     (void)hipFree(r->d_image);
     (void)hipFree(r->d_accum);
     (void)hipFree(r->d_stats);
-    free(r);
+    delete r;
     return VRC_OK;
+}
+
+void vrc::renderer_info(const vrc_renderer* r, int* device, uint32_t* width, uint32_t* height)
+{
+    *device = r->device; *width = r->width; *height = r->height;
 }
 
 extern "C" int vrc_renderer_set_primary_capture(vrc_renderer* r, vrc_hit* prim_dev)
@@ -341,8 +439,10 @@ extern "C" int vrc_render_frame(vrc_renderer* r, const vrc_camera* cam, const vr
         if (p->row_block % 8u) return fail(VRC_ERR_INVALID, "vrc_render_frame: row_block must be a multiple of 8");
         if (p->shard_index >= p->shard_count) return fail(VRC_ERR_INVALID, "vrc_render_frame: shard_index >= shard_count");
     }
+    if (p->spp > VRC_MAX_SPP) return fail(VRC_ERR_INVALID, "vrc_render_frame: spp %u > %u per call", p->spp, VRC_MAX_SPP);
     const vrc_scene* s = r->scene;
-    HIP_TRY(hipSetDevice(s->device));
+    const Tuning tuning = r->tuning;
+    HIP_TRY(hipSetDevice(r->device));
     hipStream_t st = (hipStream_t)stream;
     vrc::FrameArgs a;
     memset(&a, 0, sizeof(a));
@@ -367,69 +467,72 @@ extern "C" int vrc_render_frame(vrc_renderer* r, const vrc_camera* cam, const vr
         a.p.row_block = 0; a.p.shard_index = 0; a.p.shard_count = 1;
     }
     // checkerboard frames on the stage-synchronous kernel: 16 x 8 pixel tiles, 64 selected pixels each
-    a.checker_wide = (g_tuning.kernel == VRC_KERNEL_SYNC && p->checker_parity >= 0) ? 1u : 0u;
+    a.checker_wide = (tuning.kernel == VRC_KERNEL_SYNC && p->checker_parity >= 0) ? 1u : 0u;
     const uint32_t tiles_per_row = a.checker_wide ? (r->width + 15u) / 16u : (r->width + 7u) / 8u;
     const uint64_t items = (uint64_t)tiles_per_row * ((rows + 7u) / 8u) * 64ull;
     if (items > 0xfffffff0ull) return fail(VRC_ERR_INVALID, "vrc_render_frame: frame too large");
     a.n_items = (uint32_t)items;
-    a.chunk = g_tuning.chunk;
-    a.refill_threshold = g_tuning.refill_threshold;
+    a.chunk = tuning.chunk;
+    a.refill_threshold = tuning.refill_threshold;
     if (a.n_items == 0) return VRC_OK;
     if (!r->queue_clean) HIP_TRY(hipMemsetAsync(a.queue, 0, vrc::VRC_QUEUE_BYTES, st));
     r->queue_clean = false;
     uint64_t want = (items + VRC_RENDER_BLOCK - 1) / VRC_RENDER_BLOCK;
     // k_render_tile: (depth-1)*2 KiB of stacks + 21 KiB of job pools + 1.5 KiB of tables per workgroup
     // (38.5 KiB at depth 9): at most 4 fit a CU's 160 KiB; 120 VGPRs allow 4 waves per SIMD as well
-    uint32_t bpc = g_tuning.blocks_per_cu;
-    if (g_tuning.kernel == VRC_KERNEL_TILE) {
+    uint32_t bpc = tuning.blocks_per_cu;
+    if (tuning.kernel == VRC_KERNEL_TILE) {
         const uint32_t lds = (s->depth - 1) * 2048u + 4u * vrc::tile_wave_lds_bytes() + 1536u;
         const uint32_t fit = 163840u / lds;
         if (bpc > fit) bpc = fit;
         if (bpc > vrc::tile_max_blocks_per_cu()) bpc = vrc::tile_max_blocks_per_cu();
-    } else if (g_tuning.kernel == VRC_KERNEL_SYNC) {
+    } else if (tuning.kernel == VRC_KERNEL_SYNC) {
         const uint32_t lds = (s->depth - 1) * 2048u + 1536u;
         const uint32_t fit = 163840u / lds;
         bpc = vrc::sync_max_blocks_per_cu();          // its own default: as many as registers allow
-        if (g_tuning.blocks_per_cu_set && g_tuning.blocks_per_cu < bpc) bpc = g_tuning.blocks_per_cu;
+        if (tuning.blocks_per_cu_set && tuning.blocks_per_cu < bpc) bpc = tuning.blocks_per_cu;
         if (bpc > fit) bpc = fit;
     }
     const uint64_t cap = (uint64_t)s->cu_count * bpc;
     a.sample_chunk = 0;
-    if (g_tuning.kernel == VRC_KERNEL_SYNC && a.p.use_samples && a.p.spp > 1) {
+    if (tuning.kernel == VRC_KERNEL_SYNC && a.p.use_samples && a.p.spp > 1) {
         // Units should be short against the launch (its end waits for the last unit of every wave, and the oldest
         // wave of a SIMD runs ~3.6x faster than the youngest) yet not so small that the accumulator atomics and
         // queue traffic show: the largest chunk that still gives ~48 units per wave of a full grid, else 2 samples
         // per unit, else (small multi-GPU shards) 1.  Measured: C3 1.91 -> 1.83 ms, C5 26.3 -> 26.0 ms
         // (tools/chunk_time.py).
         const uint64_t tiles = a.n_items / 64, waves = cap * (VRC_RENDER_BLOCK / 64);
-        uint32_t c = g_tuning.sample_chunk ? g_tuning.sample_chunk : a.p.spp;
-        if (!g_tuning.sample_chunk) {
+        uint32_t c = tuning.sample_chunk ? tuning.sample_chunk : a.p.spp;
+        if (!tuning.sample_chunk) {
             while (c > 2 && tiles * ((a.p.spp + c - 1) / c) < 48 * waves) c = (c + 1) / 2;
             if (c == 2 && tiles * ((a.p.spp + 1) / 2) < 8 * waves) c = 1;
         }
         a.sample_chunk = c < a.p.spp ? c : 0;
         // shorter units for the tiles handed out last (about five per wave): halves the spread of the waves' end times
         uint64_t units = tiles * ((a.p.spp + c - 1) / c);
-        if (!g_tuning.sample_chunk && c >= 2 && g_tuning.tail_units_per_wave) {
+        if (!tuning.sample_chunk && c >= 2 && tuning.tail_units_per_wave) {
             const uint32_t ct = c / 2, cpt_tail = (a.p.spp + ct - 1) / ct;
-            uint64_t tt = (uint64_t)g_tuning.tail_units_per_wave * waves / cpt_tail;
+            uint64_t tt = (uint64_t)tuning.tail_units_per_wave * waves / cpt_tail;
             if (tt > tiles) tt = tiles;
             a.sample_chunk_tail = ct;
             a.tail_tiles = (uint32_t)tt;
             units = (tiles - tt) * ((a.p.spp + c - 1) / c) + tt * cpt_tail;
         }
+        // the kernel numbers work units in 32 bits
+        if (units > 0xfffffff0ull) return fail(VRC_ERR_INVALID, "vrc_render_frame: %llu work units (tiles x sample chunks) do not fit 32 bits; "
+                                               "use fewer samples per call or a larger sample chunk", (unsigned long long)units);
         // one wave per unit until the chip is full: a shard of few tiles still spreads over all CUs
         want = (units + VRC_RENDER_BLOCK / 64 - 1) / (VRC_RENDER_BLOCK / 64);
     }
     const uint32_t grid = (uint32_t)(want < cap ? want : cap);
-    HIP_TRY(vrc::launch_render(a, grid, (int)g_tuning.kernel, st));
+    HIP_TRY(vrc::launch_render(a, grid, (int)tuning.kernel, st));
     return VRC_OK;
 }
 
 extern "C" int vrc_samples_to_image(vrc_renderer* r, void* stream)
 {
     if (!r) return fail(VRC_ERR_INVALID, "null renderer");
-    HIP_TRY(hipSetDevice(r->scene->device));
+    HIP_TRY(hipSetDevice(r->device));
     HIP_TRY(vrc::launch_resolve(r->d_accum, r->d_image, r->width * r->height, (hipStream_t)stream));
     return VRC_OK;
 }
@@ -437,7 +540,7 @@ extern "C" int vrc_samples_to_image(vrc_renderer* r, void* stream)
 extern "C" int vrc_reset_samples(vrc_renderer* r, void* stream)
 {
     if (!r) return fail(VRC_ERR_INVALID, "null renderer");
-    HIP_TRY(hipSetDevice(r->scene->device));
+    HIP_TRY(hipSetDevice(r->device));
     HIP_TRY(hipMemsetAsync(r->d_accum, 0, (uint64_t)r->width * r->height * 16, (hipStream_t)stream));
     return VRC_OK;
 }
@@ -445,7 +548,7 @@ extern "C" int vrc_reset_samples(vrc_renderer* r, void* stream)
 extern "C" int vrc_clear_image(vrc_renderer* r, void* stream)
 {
     if (!r) return fail(VRC_ERR_INVALID, "null renderer");
-    HIP_TRY(hipSetDevice(r->scene->device));
+    HIP_TRY(hipSetDevice(r->device));
     HIP_TRY(vrc::launch_fill_u32(r->d_image, 0xff000000u, (uint64_t)r->width * r->height, (hipStream_t)stream));
     return VRC_OK;
 }
@@ -456,7 +559,7 @@ extern "C" void* vrc_accum_device_ptr(vrc_renderer* r) { return r ? r->d_accum :
 extern "C" int vrc_read_image(vrc_renderer* r, uint8_t* rgba_host, void* stream)
 {
     if (!r || !rgba_host) return fail(VRC_ERR_INVALID, "vrc_read_image: null argument");
-    HIP_TRY(hipSetDevice(r->scene->device));
+    HIP_TRY(hipSetDevice(r->device));
     HIP_TRY(hipMemcpyAsync(rgba_host, r->d_image, (uint64_t)r->width * r->height * 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     return VRC_OK;
@@ -465,7 +568,7 @@ extern "C" int vrc_read_image(vrc_renderer* r, uint8_t* rgba_host, void* stream)
 extern "C" int vrc_write_image(vrc_renderer* r, const uint8_t* rgba_host, void* stream)
 {
     if (!r || !rgba_host) return fail(VRC_ERR_INVALID, "vrc_write_image: null argument");
-    HIP_TRY(hipSetDevice(r->scene->device));
+    HIP_TRY(hipSetDevice(r->device));
     HIP_TRY(hipMemcpyAsync(r->d_image, rgba_host, (uint64_t)r->width * r->height * 4, hipMemcpyHostToDevice, (hipStream_t)stream));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     return VRC_OK;
@@ -474,7 +577,7 @@ extern "C" int vrc_write_image(vrc_renderer* r, const uint8_t* rgba_host, void* 
 extern "C" int vrc_read_accum(vrc_renderer* r, uint32_t* accum_host, void* stream)
 {
     if (!r || !accum_host) return fail(VRC_ERR_INVALID, "vrc_read_accum: null argument");
-    HIP_TRY(hipSetDevice(r->scene->device));
+    HIP_TRY(hipSetDevice(r->device));
     HIP_TRY(hipMemcpyAsync(accum_host, r->d_accum, (uint64_t)r->width * r->height * 16, hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     return VRC_OK;
@@ -483,7 +586,7 @@ extern "C" int vrc_read_accum(vrc_renderer* r, uint32_t* accum_host, void* strea
 extern "C" int vrc_get_stats(vrc_renderer* r, vrc_frame_stats* out, int reset, void* stream)
 {
     if (!r || !out) return fail(VRC_ERR_INVALID, "vrc_get_stats: null argument");
-    HIP_TRY(hipSetDevice(r->scene->device));
+    HIP_TRY(hipSetDevice(r->device));
     std::vector<uint64_t> slots(vrc::VRC_STAT_SLOTS * 4u);
     HIP_TRY(hipMemcpyAsync(slots.data(), r->d_stats, vrc::VRC_STATS_BYTES, hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
@@ -519,7 +622,7 @@ extern "C" int vrc_pack_shard(vrc_renderer* r, uint32_t row_block, uint32_t shar
 {
     if (!r || !dst_dev || !row_block || !shard_count || shard_index >= shard_count)
         return fail(VRC_ERR_INVALID, "vrc_pack_shard: bad argument");
-    HIP_TRY(hipSetDevice(r->scene->device));
+    HIP_TRY(hipSetDevice(r->device));
     HIP_TRY(vrc::launch_pack_shard(r->d_image, r->width, r->height, row_block, shard_index, shard_count,
                                    shard_slots(r->height, row_block, shard_count), dst_dev, (hipStream_t)stream));
     return VRC_OK;
@@ -531,7 +634,7 @@ extern "C" int vrc_resolve_shard(vrc_renderer* r, uint32_t row_block, uint32_t s
     if (!r || !shard_count || shard_index >= shard_count) return fail(VRC_ERR_INVALID, "vrc_resolve_shard: bad argument");
     if (shard_count == 1 && row_block == 0) row_block = r->height;     // the whole frame as one block
     if (!row_block) return fail(VRC_ERR_INVALID, "vrc_resolve_shard: row_block is 0");
-    HIP_TRY(hipSetDevice(r->scene->device));
+    HIP_TRY(hipSetDevice(r->device));
     uint32_t* queue = (uint32_t*)((uint8_t*)r->d_stats + vrc::VRC_STATS_BYTES);
     HIP_TRY(vrc::launch_resolve_shard(r->d_accum, r->d_image, r->width, r->height, row_block, shard_index, shard_count,
                                       shard_slots(r->height, row_block, shard_count), dst_dev, reset ? 1u : 0u, queue,
@@ -545,6 +648,11 @@ extern "C" int vrc_unpack_shards(const void* gathered_dev, uint32_t width, uint3
 {
     if (!gathered_dev || !image_dev || !row_block || !shard_count || !width || !height)
         return fail(VRC_ERR_INVALID, "vrc_unpack_shards: bad argument");
+    {   // no renderer here: launch on the device that owns the destination frame
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, image_dev) == hipSuccess) HIP_TRY(hipSetDevice(attr.device));
+        else (void)hipGetLastError();
+    }
     HIP_TRY(vrc::launch_unpack_shards(gathered_dev, width, height, row_block, shard_count,
                                       shard_slots(height, row_block, shard_count), image_dev, (hipStream_t)stream));
     return VRC_OK;

@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <new>
 #include <random>
 #include <vector>
 
@@ -210,7 +211,7 @@ int build_on_device(Vox vox, uint32_t depth, int device, int cus, vrc_scene** ou
     HIP_TRYB(hipEventElapsedTime(&ms_emit, ev[2], ev[3]));
     if (ms_out) *ms_out = ms_count + ms_emit;
     HIP_TRYB(hipMemset(d_tex, 0xff, 1536));
-    s = (vrc_scene*)calloc(1, sizeof(vrc_scene));
+    s = new (std::nothrow) vrc_scene();
     if (!s) { rc = vrc::fail(VRC_ERR_OOM, "out of host memory"); goto done; }
     s->device = device; s->cu_count = cus; s->d_nodes = d_nodes; s->d_tex = d_tex; s->n_nodes = n_nodes; s->depth = depth;
     d_nodes = nullptr; d_tex = nullptr;

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+
 #include "../../include/vrc.h"
 
 #define VRC_RENDER_BLOCK 256
@@ -13,12 +15,18 @@
 
 // opaque handles of include/vrc.h
 struct vrc_scene {
-    int device;
-    int cu_count;
-    void* d_nodes;
-    void* d_tex;  // 1536 bytes
-    uint64_t n_nodes;
-    uint32_t depth;
+    int device = 0;
+    int cu_count = 0;
+    void* d_nodes = nullptr;
+    void* d_tex = nullptr;  // 1536 bytes
+    uint64_t n_nodes = 0;
+    uint32_t depth = 0;
+    // single-ray slot of vrc_cast_ray (Camera::getClosestPoint, once per frame): 128 bytes of pinned host memory the
+    // kernel reads the ray from and writes the HitPoint to, and a stream of its own -- no allocation, no copy and no
+    // device-wide synchronisation per call.  Created on first use, guarded by the mutex (a scene is shared by threads).
+    std::mutex stage_mu;
+    void* h_stage = nullptr;
+    hipStream_t stage_stream = nullptr;
 };
 
 namespace vrc {
@@ -66,6 +74,13 @@ hipError_t launch_render(const FrameArgs& a, uint32_t grid_blocks, int kernel, h
 hipError_t launch_resolve(const void* accum, void* image, uint32_t n, hipStream_t st);
 hipError_t launch_fill_u32(void* p, uint32_t value, uint64_t n, hipStream_t st);
 hipError_t launch_sanitize_nodes(void* nodes, uint64_t n, hipStream_t st);   // leaf_mask &= child_mask
+// Structural check of a caller-supplied LNode array (vrc_scene_create): *flags_dev (one u32, zeroed by the caller) gets
+// bit 0 = a child block reaches past the array, bit 1 = a non-leaf child below the unit-voxel level (the tree is
+// deeper than `depth`), bit 2 = a node reachable at two different levels (cycle / mis-shared subtree).
+// level_dev: n bytes of scratch.
+hipError_t launch_validate_nodes(const void* nodes, uint64_t n, uint32_t depth, uint8_t* level_dev, uint32_t* flags_dev, hipStream_t st);
+void renderer_info(const vrc_renderer* r, int* device, uint32_t* width, uint32_t* height);
+void scene_free(vrc_scene* s);   // releases the device / pinned resources and deletes s
 hipError_t launch_pack_shard(const void* image, uint32_t W, uint32_t H, uint32_t row_block, uint32_t shard,
                              uint32_t count, uint32_t slots, void* dst, hipStream_t st);
 hipError_t launch_resolve_shard(void* accum, void* image, uint32_t W, uint32_t H, uint32_t row_block, uint32_t shard,

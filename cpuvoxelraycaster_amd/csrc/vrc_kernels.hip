@@ -1167,6 +1167,29 @@ extern "C" __global__ void k_sanitize_nodes(uint2* __restrict__ nodes, uint64_t 
     if (y != x) nodes[i].x = y;
 }
 
+// vrc_scene_create: structural validation of a caller-supplied array, so that a truncated or malformed one is an error
+// code and not an out-of-bounds gather in the walk.  Pass L visits the nodes first reached at level L (root = 0) and
+// hands level L + 1 to the child blocks of their non-leaf children.
+extern "C" __global__ void k_validate_level(const uint2* __restrict__ nodes, uint64_t n, uint32_t depth, uint32_t L,
+                                            uint8_t* __restrict__ level, uint32_t* __restrict__ flags)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || level[i] != (uint8_t)L) return;
+    const uint2 nd = nodes[i];
+    const uint32_t internal = (nd.x >> 8) & 0xffu & ~(nd.x >> 16);   // children that exist and are not leaves
+    if (!internal) return;
+    if (L + 1u >= depth) { atomicOr(flags, 2u); return; }            // would descend below the unit voxels
+    const uint32_t hi = 31u - (uint32_t)__clz((int)internal);
+    if (i + (uint64_t)nd.y + hi >= n) { atomicOr(flags, 1u); return; }
+    for (uint32_t c = 0; c < 8u; ++c) {
+        if (!((internal >> c) & 1u)) continue;
+        const uint64_t k = i + nd.y + c;
+        const uint8_t seen = level[k];
+        if (seen == 0xffu) level[k] = (uint8_t)(L + 1u);            // every writer of this pass writes the same value
+        else if (seen != (uint8_t)(L + 1u)) atomicOr(flags, 4u);
+    }
+}
+
 // compact the row blocks owned by `shard` into dst: slot k <- block shard + k*count
 extern "C" __global__ void k_pack_shard(const uint32_t* __restrict__ image, uint32_t W, uint32_t H, uint32_t row_block,
                                         uint32_t shard, uint32_t count, uint32_t slots, uint32_t* __restrict__ dst)
@@ -1286,6 +1309,18 @@ hipError_t launch_sanitize_nodes(void* nodes, uint64_t n, hipStream_t st)
 {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_sanitize_nodes, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, (uint2*)nodes, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_validate_nodes(const void* nodes, uint64_t n, uint32_t depth, uint8_t* level_dev, uint32_t* flags_dev, hipStream_t st)
+{
+    if (n == 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(level_dev, 0xff, n, st);
+    if (e == hipSuccess) e = hipMemsetAsync(level_dev, 0, 1, st);    // the root
+    if (e != hipSuccess) return e;
+    for (uint32_t L = 0; L < depth; ++L)
+        hipLaunchKernelGGL(k_validate_level, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, (const uint2*)nodes, n, depth, L,
+                           level_dev, flags_dev);
     return hipGetLastError();
 }
 

@@ -2,8 +2,10 @@
 read-only LSVO replicated, the frame sharded by interleaved ROW_BLOCK-row
 blocks (block b belongs to rank b % world), RNG keyed by the global pixel index
 so the image does not depend on the GPU count.  The only exchange step is one
-all-gather of the resolved RGBA8 shards per frame (RCCL over xGMI on the GPU
-box; the same code runs over gloo on CPU tensors in the tests).
+collective over the resolved RGBA8 shards per frame (RCCL over xGMI on the GPU
+box; the same code runs over gloo on CPU tensors in the tests): an all-gather
+(every rank ends up with the frame) or a gather to rank 0, the presenting rank
+(north_star / SURVEY 8e; 1/N of the bytes on the wire, one direct hop per peer).
 
 Shard buffer layout (what vrc_pack_shard writes and vrc_unpack_shards reads):
     gathered[rank][slot][row_in_block][x]  RGBA8, slot k <-> row block rank + k*world,
@@ -61,6 +63,19 @@ def all_gather_frame(mine, world):
     gathered = torch.empty(world * mine.numel(), dtype=torch.uint8, device=mine.device)
     dist.all_gather_into_tensor(gathered, mine)
     return gathered
+
+
+def exchange_shards(mine, gathered, world, rank, mode="all", async_op=False):
+    """The frame's one exchange step.  mine: this rank's packed shard; gathered: world * mine.numel() bytes laid out
+    [rank][slot]...  mode "all": all-gather into every rank's `gathered`; mode "root": gather to rank 0 -- only rank
+    0's `gathered` is written (the other ranks may pass None).  Returns the work handle when async_op."""
+    import torch.distributed as dist
+    if mode == "root":
+        views = list(gathered.view(world, mine.numel()).unbind(0)) if rank == 0 else None
+        return dist.gather(mine, views, dst=0, async_op=async_op)
+    if mode != "all":
+        raise ValueError(f"unknown exchange mode {mode!r}")
+    return dist.all_gather_into_tensor(gathered, mine, async_op=async_op)
 
 
 def reduce_stats(values, device):

@@ -186,6 +186,8 @@ public:
         return s;
     }
 
+    vrc_renderer* handle() const { return r_; }
+
     bool use_gi = false;        // raycaster.hpp:274
     bool use_samples = false;   // raycaster.hpp:275
     uint32_t seed = 0x9E3779B9u;
@@ -196,6 +198,39 @@ private:
     uint32_t frame_index_ = 0;
     uint32_t row_block_ = 0, shard_index_ = 0, shard_count_ = 1;
     Vec3 light_{0, 0, 0};
+};
+
+// The blend / upscale chain main.cpp runs on render_image after every frame (main.cpp:160-182: render_tex,
+// denoised_tex, final_sprite), device resident.  present() replaces lines 160-181; the window image stays in HBM
+// (window_device_ptr) or is copied out (window()).
+class HipPresenter {
+public:
+    HipPresenter(uint32_t render_width, uint32_t render_height, uint32_t win_width, uint32_t win_height, int device = 0)
+        : out_w_(win_width), out_h_(win_height)
+    {
+        check(vrc_presenter_create(device, render_width, render_height, win_width, win_height, &p_), "vrc_presenter_create");
+    }
+    ~HipPresenter() { vrc_presenter_destroy(p_); }
+    HipPresenter(const HipPresenter&) = delete;
+    HipPresenter& operator=(const HipPresenter&) = delete;
+
+    // old_value_conservation as main.cpp:161 computes it from raycaster.use_samples
+    void present(HipRayCaster& raycaster, uint32_t median = 0, void* stream = nullptr)
+    {
+        const float old_value_conservation = raycaster.use_samples ? 0.0f : 0.1f;
+        check(vrc_present(p_, raycaster.handle(), old_value_conservation, median, stream), "vrc_present");
+    }
+    void* window_device_ptr() const { return vrc_presenter_window_ptr(p_); }
+    std::vector<uint8_t> window() const
+    {
+        std::vector<uint8_t> img((size_t)out_w_ * out_h_ * 4);
+        check(vrc_presenter_read(p_, img.data(), nullptr, nullptr), "vrc_presenter_read");
+        return img;
+    }
+
+private:
+    vrc_presenter* p_ = nullptr;
+    uint32_t out_w_, out_h_;
 };
 
 // Camera-path replay (include/replay.hpp:8-35): whitespace-separated ticks

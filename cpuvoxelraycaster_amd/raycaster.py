@@ -6,6 +6,7 @@ over the C ABI (include/vrc.h).  Names follow the reference:
   RayCaster.renderFrame        <- the swarm lambda: getRay + renderRay per pixel (src/main.cpp:139-152)
   RayCaster.samples_to_image   <- raycaster.hpp:94
   RayCaster.resetSamples       <- raycaster.hpp:105
+  Presenter.present            <- the SFML blend / upscale chain after the frame (src/main.cpp:160-182)
 
 All compute runs in the HIP kernels of libvrc_hip.so; numpy / torch are only
 used to hold buffers."""
@@ -197,6 +198,16 @@ class RayCaster:
         check(capi.load().vrc_render_frame(self._h, C.byref(camera), C.byref(p), ptr(stream)))
         self.frame_index += spp
 
+    # scheduling knobs of THIS renderer (results never depend on them; see include/vrc.h)
+    def setKernel(self, kernel):
+        check(capi.load().vrc_renderer_set_kernel(self._h, kernel))
+
+    def setTuning(self, blocks_per_cu=0, refill_threshold=0, chunk=0):
+        check(capi.load().vrc_renderer_set_tuning(self._h, blocks_per_cu, refill_threshold, chunk))
+
+    def setSampleChunk(self, samples_per_unit):
+        check(capi.load().vrc_renderer_set_sample_chunk(self._h, samples_per_unit))
+
     def setPrimaryCapture(self, dev_ptr):
         check(capi.load().vrc_renderer_set_primary_capture(self._h, ptr(dev_ptr)))
 
@@ -242,6 +253,50 @@ class RayCaster:
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
             capi.load().vrc_renderer_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Presenter:
+    """main.cpp:160-182 on the device: render_tex / denoised_tex persistence blend, nearest upscale to the window size,
+    optional median (res/median_3.frag, res/median.frag).  Owns denoised_tex and the window image."""
+
+    def __init__(self, render_size, window_size, device=0):
+        self.width, self.height = int(render_size[0]), int(render_size[1])
+        self.out_width, self.out_height = int(window_size[0]), int(window_size[1])
+        self._h = C.c_void_p()
+        check(capi.load().vrc_presenter_create(device, self.width, self.height, self.out_width, self.out_height, C.byref(self._h)))
+
+    def present(self, raycaster, old_value_conservation=None, median=0, stream=None):
+        """old_value_conservation defaults to main.cpp:161: use_samples ? 0 : 0.1"""
+        if old_value_conservation is None:
+            old_value_conservation = 0.0 if raycaster.use_samples else 0.1
+        check(capi.load().vrc_present(self._h, raycaster._h, old_value_conservation, median, ptr(stream)))
+
+    def presentImage(self, image_dev_ptr, old_value_conservation, median=0, stream=None):
+        check(capi.load().vrc_present_image(self._h, ptr(image_dev_ptr), old_value_conservation, median, ptr(stream)))
+
+    def clear(self, stream=None):
+        check(capi.load().vrc_presenter_clear(self._h, ptr(stream)))
+
+    def window_ptr(self):
+        return capi.load().vrc_presenter_window_ptr(self._h)
+
+    def read(self, stream=None):
+        """(window RGBA8 (out_h, out_w, 4), denoised_tex RGBA8 (h, w, 4))"""
+        win = np.zeros((self.out_height, self.out_width, 4), np.uint8)
+        den = np.zeros((self.height, self.width, 4), np.uint8)
+        check(capi.load().vrc_presenter_read(self._h, ptr(win), ptr(den), ptr(stream)))
+        return win, den
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            capi.load().vrc_presenter_destroy(self._h)
             self._h = None
 
     def __del__(self):

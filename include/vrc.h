@@ -78,7 +78,12 @@ int vrc_device_count(void);                /* >= 0, or VRC_ERR_NO_DEVICE */
 /* ---- scene: LSVO<N> (lsvo.hpp:12-24) ---------------------------------- */
 
 /* Copies `n_nodes` LNodes (host memory) to `device` and keeps them resident.
- * Replaces LSVO(const SVO<N>&) + compileSVO for a pre-compiled array. */
+ * Replaces LSVO(const SVO<N>&) + compileSVO for a pre-compiled array.  The array
+ * is checked once, on the device: every non-leaf child's 8-slot block must lie
+ * inside the array, the tree must not be deeper than `depth` levels (children of
+ * level depth-1 nodes are unit-voxel leaves, lsvo.hpp:90-95), and no node may be
+ * reachable at two different levels; a malformed or truncated array is
+ * VRC_ERR_INVALID, never an out-of-bounds read in the walk. */
 int vrc_scene_create(const vrc_lnode *lnodes, uint64_t n_nodes, uint32_t depth,
                      int device, vrc_scene **out);
 /* 16x16 RGB tables, top-down rows, as sf::Image::getPixel sees
@@ -129,7 +134,9 @@ int vrc_cast_rays(const vrc_scene *s, uint64_t n,
                   const float *coef, const float *bias,
                   vrc_hit *out, int mem, void *stream);
 
-/* Single-ray form for Camera::getClosestPoint (camera_controller.hpp:56-60). Synchronous. */
+/* Single-ray form for Camera::getClosestPoint (camera_controller.hpp:56-60). Synchronous; thread-safe
+ * (calls on one scene are serialised).  Uses a pinned slot and a stream owned by the scene: no
+ * allocation, no device-wide synchronisation, frames in flight on other streams are not disturbed. */
 int vrc_cast_ray(const vrc_scene *s, const float org[3], const float dir[3],
                  float ray_size_coef, float ray_size_bias, vrc_hit *out);
 
@@ -161,7 +168,7 @@ typedef struct vrc_frame_params {
     uint32_t shadow_samples;  /* 0 = reference default: use_samples ? 4 : 1 (raycaster.hpp:147) */
     uint32_t gi_bounces;      /* 0/1 = reference (one indirect bounce); 2 = extension */
     int32_t checker_parity;   /* -1 = every pixel; 0/1 = checker_board_offset (main.cpp:137,143) */
-    uint32_t spp;             /* renderRay-equivalents per pixel in this call (>= 1) */
+    uint32_t spp;             /* renderRay-equivalents per pixel in this call (1 .. 65536) */
     uint32_t seed;            /* counter-based RNG key ... */
     uint32_t frame_index;     /* ... sample s of this call uses frame_index + s */
     uint32_t row_block;       /* multi-GPU: rows per shard block (0 = whole frame) */
@@ -177,7 +184,11 @@ typedef struct vrc_frame_stats {
 } vrc_frame_stats;
 
 /* RayCaster(svo, render_size) (raycaster.hpp:48-60): framebuffer cleared to
- * opaque black (sf::Image::create), accumulators zero. */
+ * opaque black (sf::Image::create), accumulators zero.  The scene must outlive
+ * every vrc_render_frame call on the renderer (as `const LSVO<9>& svo` must
+ * outlive the RayCaster, raycaster.hpp:265); the other renderer calls and
+ * vrc_renderer_destroy do not touch it.  The renderer takes a snapshot of the
+ * process-wide scheduling defaults (vrc_set_*) at creation. */
 int vrc_renderer_create(const vrc_scene *s, uint32_t width, uint32_t height, vrc_renderer **out);
 int vrc_renderer_destroy(vrc_renderer *r);
 
@@ -216,13 +227,44 @@ int vrc_pack_shard(vrc_renderer *r, uint32_t row_block, uint32_t shard_index, ui
  * shard_count == 1 with row_block == 0 covers the whole frame (dst_dev layout == image layout). */
 int vrc_resolve_shard(vrc_renderer *r, uint32_t row_block, uint32_t shard_index, uint32_t shard_count,
                       void *dst_dev, int reset, void *stream);
+/* Launches on the device that owns image_dev. */
 int vrc_unpack_shards(const void *gathered_dev, uint32_t width, uint32_t height, uint32_t row_block,
                       uint32_t shard_count, void *image_dev, void *stream);
+
+/* ---- post-process / present chain that follows the path (main.cpp:160-182) ---------- */
+
+/* Device-resident restatement of what main.cpp does with render_image every frame, so that the frame stays in
+ * HBM between the renderer and whatever shows it (no PCIe read-back):
+ *   render_tex   = render_image x Color(255 * (1 - old))                        (sf::BlendMultiply, :163-172)
+ *   denoised_tex = denoised_tex x Color(255 * old) + render_tex, saturating     (BlendMultiply, BlendAdd, :161-162,175-177)
+ *   window       = denoised_tex scaled to out_width x out_height, nearest       (final_sprite.setScale(1 / 0.75), :179-182)
+ * with old = old_value_conservation (main.cpp:161: use_samples ? 0 : 0.1), and an optional per-channel median around
+ * the sampled texel: median = 0 none, 3 = the 3x3 network of res/median_3.frag, 5 = the 5x5 network of
+ * res/median.frag as shipped (taps one texel apart, clamped to the edge).  UNORM8 products are rounded to nearest,
+ * round(a * b / 255) -- fixed-function GL blending is not specified bit-exactly, so against a real GL device the two
+ * blend steps carry a tolerance of +-1 LSB each; upscale and median are exact.  The presenter owns denoised_tex
+ * (zero at creation, persistent across frames) and the window image. */
+typedef struct vrc_presenter vrc_presenter;
+int vrc_presenter_create(int device, uint32_t width, uint32_t height, uint32_t out_width, uint32_t out_height,
+                         vrc_presenter **out);
+int vrc_presenter_destroy(vrc_presenter *p);
+/* One frame of the chain on the renderer's framebuffer (same device, same size).  Asynchronous on `stream`. */
+int vrc_present(vrc_presenter *p, vrc_renderer *r, float old_value_conservation, uint32_t median, void *stream);
+/* The same on any device-resident RGBA8 image of the presenter's render size (e.g. a gathered multi-GPU frame). */
+int vrc_present_image(vrc_presenter *p, const void *image_dev, float old_value_conservation, uint32_t median, void *stream);
+int vrc_presenter_clear(vrc_presenter *p, void *stream);          /* denoised_tex = 0 */
+void *vrc_presenter_window_ptr(vrc_presenter *p);                 /* RGBA8 out_width x out_height, device */
+void *vrc_presenter_denoised_ptr(vrc_presenter *p);               /* RGBA8 width x height, device */
+/* Copies the window image and / or denoised_tex to host memory (either may be NULL).  Synchronous. */
+int vrc_presenter_read(vrc_presenter *p, uint8_t *window_rgba_host, uint8_t *denoised_rgba_host, void *stream);
 
 /* Host helper: generateRotationMatrix (utils.cpp:94-100) for Camera::setViewAngle. */
 void vrc_make_rotation(float angle_x, float angle_y, float rot[9]);
 
-/* Tuning knobs of the persistent frame kernel; 0 = default.
+/* Scheduling knobs.  vrc_set_* change the process-wide DEFAULTS that new renderers copy at
+ * creation (thread-safe); vrc_renderer_set_* change one renderer (a renderer is not re-entrant,
+ * so call them between its frames).  Results never depend on them.
+ * Tuning knobs of the persistent frame kernel; 0 = default.
  * blocks_per_cu: resident 256-thread workgroups per CU (default 4);
  * refill_threshold: waiting lanes per wave that trigger a refill (default 32);
  * chunk: consecutive work items (pixels in 8x8-tile order) a wave reserves per
@@ -241,6 +283,9 @@ int vrc_set_kernel(uint32_t kernel);
  * units are accumulated with integer atomics (same sums).  Values >= 0xffff0000 set the
  * automatic mode's tail policy instead: low 16 bits = units per wave with the halved chunk. */
 int vrc_set_sample_chunk(uint32_t samples_per_unit);
+int vrc_renderer_set_tuning(vrc_renderer *r, uint32_t blocks_per_cu, uint32_t refill_threshold, uint32_t chunk);
+int vrc_renderer_set_kernel(vrc_renderer *r, uint32_t kernel);
+int vrc_renderer_set_sample_chunk(vrc_renderer *r, uint32_t samples_per_unit);
 
 #ifdef __cplusplus
 }

@@ -911,6 +911,35 @@ void orc_render_frame_trace(const orc_lnode *nodes, uint32_t depth,
     if (stats) { stats->rays = rays; stats->sum_complexity = sumc; stats->primary_hits = hits; }
 }
 
+/* The same frame with the REFERENCE's own decomposition (main.cpp:90-92,139-152): 16 threads, thread t owns the
+ * area (t % 4, t / 4) of (W/4) x (H/4) pixels and walks it x-outer / y-inner; pixels beyond 4*(W/4) x 4*(H/4) are
+ * never rendered (as in the reference).  Static assignment, no work stealing: the frame takes as long as its
+ * slowest area.  Used by bench.py's cpu_baseline leg ("decomp": "4x4x16"); results are identical to
+ * orc_render_frame on the pixels both render. */
+void orc_render_frame_areas16(const orc_lnode *nodes, uint32_t depth,
+                              const uint8_t tex_top[768], const uint8_t tex_side[768],
+                              const orc_camera *cam, const orc_frame_params *p,
+                              uint8_t *image, uint32_t *accum, orc_frame_stats *stats)
+{
+    const uint32_t aw = p->width / 4u, ah = p->height / 4u;
+    uint64_t rays = 0, sumc = 0;
+#pragma omp parallel num_threads(16) reduction(+ : rays, sumc)
+    {
+#pragma omp for schedule(static, 1)
+        for (int t = 0; t < 16; t++) {
+            shade_ctx c = { nodes, depth, tex_top, tex_side,
+                            { p->light_position[0], p->light_position[1], p->light_position[2] }, 0, 0, 0, 0 };
+            const uint32_t x0 = ((uint32_t)t % 4u) * aw, y0 = ((uint32_t)t / 4u) * ah;
+            for (uint32_t x = x0; x < x0 + aw; x++)
+                for (uint32_t y = y0; y < y0 + ah; y++)
+                    if (pixel_selected(p, x, y))
+                        render_pixel(&c, cam, p, x, y, image, accum, 0, 0);
+            rays += c.rays; sumc += c.sum_complexity;
+        }
+    }
+    if (stats) { stats->rays = rays; stats->sum_complexity = sumc; stats->primary_hits = 0; }
+}
+
 /* raycaster.hpp:94-103: uint8(sum / count) in double == integer division for
  * integer sums (see vrc_oracle.h).  count == 0 (never-sampled pixel) is NaN ->
  * UB in the reference; black here. */
@@ -923,5 +952,106 @@ void orc_samples_to_image(const uint32_t *accum, uint32_t width, uint32_t height
             image[i * 4 + k] = (uint8_t)v;
         }
         image[i * 4 + 3] = 255;
+    }
+}
+
+
+/* ------------------------------------------------------------------------- */
+/* N2: frame post-process / present chain (main.cpp:160-182)                  */
+/* ------------------------------------------------------------------------- */
+
+/* Fixed-function GL blending on an RGBA8 render target, restated in integers: a UNORM8 product a/255 * b/255 is
+ * stored as round(a*b/255) (OpenGL 4.x 2.3.5: conversion to UNORM rounds to nearest; 255 is odd, so there are no
+ * ties).  Hardware may differ from this by one LSB -- that is the stated tolerance of the blend steps against a real
+ * GL device; the HIP path equals THIS definition bit for bit. */
+static inline uint8_t unorm8_mul(uint32_t a, uint32_t b) { return (uint8_t)((a * b + 127u) / 255u); }
+
+/* Median of 9 / 25 values as the min/max exchange networks of res/median_3.frag and res/median.frag
+ * (McGuire & Whitson, 2006; the exchange lists are data, written out in vrc_present.hip's tables too).
+ *   s2(a, b): t = a; a = min(a, b); b = max(t, b) */
+#define ORC_S2(a, b) do { const uint8_t t_ = (a); (a) = (a) < (b) ? (a) : (b); (b) = t_ > (b) ? t_ : (b); } while (0)
+
+static uint8_t median9_net(const uint8_t w[9])
+{
+    /* median_3.frag:57-82; w in fetch order (-1,-1) (0,-1) (+1,-1) (-1,0) (0,0) (+1,0) (-1,+1) (0,+1) (+1,+1) */
+    uint8_t v[6] = { w[0], w[1], w[2], w[3], w[4], w[5] };
+    ORC_S2(v[0], v[3]); ORC_S2(v[1], v[4]); ORC_S2(v[2], v[5]);            /* mnmx6 */
+    ORC_S2(v[0], v[1]); ORC_S2(v[0], v[2]);
+    ORC_S2(v[4], v[5]); ORC_S2(v[3], v[5]);
+    v[5] = w[6];
+    ORC_S2(v[1], v[2]); ORC_S2(v[3], v[4]);                                /* mnmx5 */
+    ORC_S2(v[1], v[3]); ORC_S2(v[1], v[5]);
+    ORC_S2(v[4], v[5]); ORC_S2(v[2], v[5]);
+    v[5] = w[7];
+    ORC_S2(v[2], v[3]); ORC_S2(v[4], v[5]); ORC_S2(v[2], v[4]); ORC_S2(v[3], v[5]);   /* mnmx4 */
+    v[5] = w[8];
+    ORC_S2(v[4], v[5]); ORC_S2(v[3], v[5]); ORC_S2(v[3], v[4]);            /* mnmx3 */
+    return v[4];
+}
+
+static const uint8_t MEDIAN25_PAIRS[][2] = {                               /* median.frag:68-86 */
+    {0,1},{3,4},{2,4},{2,3},{6,7}, {5,7},{5,6},{9,7},{1,7},{1,4}, {12,13},{11,13},{11,12},{15,16},{14,16},
+    {14,15},{18,19},{17,19},{17,18},{21,22}, {20,22},{20,21},{23,24},{2,5},{3,6}, {0,6},{0,3},{4,7},{1,7},{1,4},
+    {11,14},{8,14},{8,11},{12,15},{9,15}, {9,12},{13,16},{10,16},{10,13},{20,23}, {17,23},{17,20},{21,24},{18,24},{18,21},
+    {19,22},{8,17},{9,18},{0,18},{0,9}, {10,19},{1,19},{1,10},{11,20},{2,20}, {2,11},{12,21},{3,21},{3,12},{13,22},
+    {4,22},{4,13},{14,23},{5,23},{5,14}, {15,24},{6,24},{6,15},{7,16},{7,19}, {3,11},{5,17},{11,17},{9,17},{4,10},
+    {6,12},{7,14},{4,6},{4,7},{12,14}, {10,14},{6,7},{10,12},{6,10},{6,17}, {12,17},{7,17},{7,10},{12,18},{7,12},
+    {10,18},{12,20},{10,20},{10,12},
+};
+
+static uint8_t median25_net(uint8_t v[25])
+{
+    for (size_t i = 0; i < sizeof(MEDIAN25_PAIRS) / sizeof(MEDIAN25_PAIRS[0]); i++)
+        ORC_S2(v[MEDIAN25_PAIRS[i][0]], v[MEDIAN25_PAIRS[i][1]]);
+    return v[12];
+}
+
+static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+void orc_present(const uint8_t *image, uint8_t *denoised, uint32_t width, uint32_t height,
+                 float old_value_conservation, uint32_t median, uint8_t *window, uint32_t out_width, uint32_t out_height)
+{
+    /* main.cpp:161-166: sf::Color(255 * c, ...) truncates the float to Uint8 */
+    const uint32_t c1 = (uint32_t)(uint8_t)(255 * old_value_conservation);
+    const uint32_t c2 = (uint32_t)(uint8_t)(255 * (1.0f - old_value_conservation));
+    const uint64_t n = (uint64_t)width * height;
+    for (uint64_t i = 0; i < n; i++) {
+        for (int k = 0; k < 3; k++) {
+            const uint32_t r = unorm8_mul(image[i * 4 + k], c2);            /* :169-172 sprite drawn opaque, then x cache2 (BlendMultiply) */
+            const uint32_t d = unorm8_mul(denoised[i * 4 + k], c1);         /* :175 denoised x cache1 (BlendMultiply) */
+            const uint32_t sum = d + r;                                     /* :176-177 BlendAdd: src * srcAlpha(=1) + dst, clamped */
+            denoised[i * 4 + k] = (uint8_t)(sum > 255u ? 255u : sum);
+        }
+        denoised[i * 4 + 3] = 255;                                          /* alpha: 255 * 255 / 255, then min(1, a + a) */
+    }
+    if (!window) return;
+    /* :179-182: the sprite scaled by 1 / render_scale with nearest sampling (textures are not smooth): window pixel
+     * (X, Y) takes the texel that contains (X + 0.5) * width / out_width; optional median around that texel, taps clamped
+     * to the edge (SFML textures are not repeated), exactly one texel apart (the shaders hard-code 1/800) */
+    for (uint32_t Y = 0; Y < out_height; Y++) {
+        const uint32_t sy = (uint32_t)(((uint64_t)(2u * Y + 1u) * height) / (2ull * out_height));
+        for (uint32_t X = 0; X < out_width; X++) {
+            const uint32_t sx = (uint32_t)(((uint64_t)(2u * X + 1u) * width) / (2ull * out_width));
+            uint8_t *o = window + ((uint64_t)Y * out_width + X) * 4;
+            for (int k = 0; k < 3; k++) {
+                if (median == 3) {
+                    uint8_t w[9];
+                    int q = 0;
+                    for (int dy = -1; dy <= 1; dy++)
+                        for (int dx = -1; dx <= 1; dx++)
+                            w[q++] = denoised[((uint64_t)clampi((int)sy + dy, 0, (int)height - 1) * width + (uint32_t)clampi((int)sx + dx, 0, (int)width - 1)) * 4 + k];
+                    o[k] = median9_net(w);
+                } else if (median == 5) {
+                    uint8_t v[25];
+                    for (int dX = -2; dX <= 2; dX++)                         /* median.frag:54-62: v[(dX + 2) * 5 + (dY + 2)] */
+                        for (int dY = -2; dY <= 2; dY++)
+                            v[(dX + 2) * 5 + (dY + 2)] = denoised[((uint64_t)clampi((int)sy + dY, 0, (int)height - 1) * width + (uint32_t)clampi((int)sx + dX, 0, (int)width - 1)) * 4 + k];
+                    o[k] = median25_net(v);
+                } else {
+                    o[k] = denoised[((uint64_t)sy * width + sx) * 4 + k];
+                }
+            }
+            o[3] = 255;
+        }
     }
 }

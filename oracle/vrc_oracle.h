@@ -145,6 +145,12 @@ void orc_render_frame(const orc_lnode *nodes, uint32_t depth,
                       const orc_camera *cam, const orc_frame_params *p,
                       uint8_t *image, uint32_t *accum, orc_hit *prim,
                       orc_frame_stats *stats, int threads);
+/* orc_render_frame with the reference's thread decomposition: 16 threads x static 4x4 areas, x-outer / y-inner
+ * (main.cpp:90-92,139-152); the CPU-baseline variant SURVEY 8d asks for. */
+void orc_render_frame_areas16(const orc_lnode *nodes, uint32_t depth,
+                              const uint8_t tex_top[768], const uint8_t tex_side[768],
+                              const orc_camera *cam, const orc_frame_params *p,
+                              uint8_t *image, uint32_t *accum, orc_frame_stats *stats);
 /* Analysis hook (tools/): the same frame, and per pixel the loop-iteration counts of its first ORC_TRACE_RAYS
  * castRay calls in cast order (primary, shadow..., GI, GI shadow, ...) into trace[pixel * ORC_TRACE_RAYS + k]
  * (untouched entries stay as the caller set them).  trace == NULL is orc_render_frame. */
@@ -156,6 +162,15 @@ void orc_render_frame_trace(const orc_lnode *nodes, uint32_t depth,
                             orc_frame_stats *stats, int threads, uint16_t *trace);
 /* raycaster.hpp:94-103 / :105-116 */
 void orc_samples_to_image(const uint32_t *accum, uint32_t width, uint32_t height, uint8_t *image);
+
+/* ---- N2: post-process / present chain (main.cpp:160-182; res/median_3.frag, res/median.frag) ----
+ * image: the RayCaster's render_image (RGBA8, width x height).  denoised: the persistent denoised_tex, updated in
+ * place: denoised = sat(round(denoised * c1 / 255) + round(image * c2 / 255)), c1 = uint8(255 * old), c2 = uint8(255 *
+ * (1 - old)) (main.cpp:161-166; old = use_samples ? 0 : 0.1).  window (optional): out_width x out_height RGBA8 = the
+ * denoised image scaled with nearest sampling (main.cpp:179-181, scale 1 / 0.75), through an optional per-channel
+ * median (0 = none, 3 = 3x3, 5 = 5x5: the shaders' min/max networks, taps one texel apart, clamped to the edge). */
+void orc_present(const uint8_t *image, uint8_t *denoised, uint32_t width, uint32_t height,
+                 float old_value_conservation, uint32_t median, uint8_t *window, uint32_t out_width, uint32_t out_height);
 
 #ifdef __cplusplus
 }

@@ -49,6 +49,17 @@ def _worker(rank, world, port, W, H, q):
     assert mine.numel() == vd.shard_bytes(W, H, vd.ROW_BLOCK, world)
     gathered = vd.all_gather_frame(mine, world)
     full = vd.unpack_shards_np(gathered.numpy(), W, H, vd.ROW_BLOCK, world)
+    # the two exchange forms bench.py offers (--gather all / root), synchronous and asynchronous
+    for mode in ("all", "root"):
+        for async_op in (False, True):
+            buf = torch.zeros(world * mine.numel(), dtype=torch.uint8)
+            work = vd.exchange_shards(mine, buf, world, rank, mode, async_op=async_op)
+            if async_op:
+                work.wait()
+            if mode == "all" or rank == 0:
+                assert torch.equal(buf, gathered), (mode, async_op)
+            else:
+                assert not buf.any()                      # a gather writes on the presenting rank only
     tot = vd.reduce_stats([rays, steps], "cpu")
     if rank == 0:
         q.put((full, tot))

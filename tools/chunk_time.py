@@ -34,10 +34,10 @@ def main():
     for r in range(args.rounds + 1):
         for c in chunks:
             if isinstance(c, tuple):
-                vrc.capi.check(L.vrc_set_sample_chunk(0))
-                vrc.capi.check(L.vrc_set_sample_chunk(0xffff0000 | c[1]))
+                rc.setSampleChunk(0)
+                rc.setSampleChunk(0xffff0000 | c[1])
             else:
-                vrc.capi.check(L.vrc_set_sample_chunk(c))
+                rc.setSampleChunk(c)
             for f in range(3):
                 rc.resetSamples(stream)
                 rc.frame_index = 0

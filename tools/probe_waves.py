@@ -31,7 +31,7 @@ def main():
     cam = vrc.reference_camera(depth, pitch=-0.5, aperture=cfg["aperture"])
     stream = torch.cuda.current_stream().cuda_stream
     L = vrc.capi.load()
-    vrc.capi.check(L.vrc_set_sample_chunk(args.chunk))
+    rc.setSampleChunk(args.chunk)
     probe = torch.zeros(W * H * 12, dtype=torch.int32, device="cuda")
     rc.setPrimaryCapture(probe.data_ptr())
     n_units = ((W + 7) // 8) * ((H + 7) // 8) * (spp // args.chunk if args.chunk else 1)

@@ -38,8 +38,8 @@ def main():
     times = {c: [] for c in combos}
     for r in range(args.rounds + 1):
         for c in combos:
-            vrc.capi.check(L.vrc_set_kernel(c[0]))
-            vrc.capi.check(L.vrc_set_tuning(*c[1:]))
+            rc.setKernel(c[0])
+            rc.setTuning(*c[1:])
             for f in range(args.frames):
                 rc.resetSamples(stream)
                 rc.frame_index = 0
