@@ -54,6 +54,17 @@ __device__ __forceinline__ void normalize3(float& x, float& y, float& z)
     x = x * inv; y = y * inv; z = z * inv;
 }
 
+// 1 / x, correctly rounded, for 2^-126 <= x < 2^126 (see ray_setup): y0 = v_rcp_f32(x) is within 1 ulp; the residual
+// e = 1 - x * y0 is exact in one FMA, and y0 + y0 * e rounds to the nearest float of the true quotient.  These two FMAs
+// are the Newton step itself, not a contraction of reference arithmetic (the reference's operation here is one division).
+__device__ __forceinline__ float exact_rcp(float x)
+{
+    float y0;
+    asm("v_rcp_f32_e32 %0, %1" : "=v"(y0) : "v"(x));
+    const float e = __builtin_fmaf(-x, y0, 1.0f);
+    return __builtin_fmaf(y0, e, y0);
+}
+
 // Counter-based RNG replacing the reference's racy global xorshf96
 // (utils.cpp:11-25); identical integer arithmetic to oracle/vrc_oracle.c.
 __device__ __forceinline__ uint32_t mix32(uint32_t x)
@@ -117,7 +128,16 @@ __device__ __forceinline__ bool ray_setup(Ray& r, const uint2 root,
     if (fabsf(dx) < EPS) dx = copysignf(EPS, dx);
     if (fabsf(dy) < EPS) dy = copysignf(EPS, dy);
     if (fabsf(dz) < EPS) dz = copysignf(EPS, dz);
-    r.tcx = -1.0f / fabsf(dx); r.tcy = -1.0f / fabsf(dy); r.tcz = -1.0f / fabsf(dz);
+    // :47  t_coef = -1 / |d|, correctly rounded.  For 2^-126 <= x < 2^126 one Newton step on v_rcp_f32 with two FMAs IS the
+    // correctly rounded quotient (tools/micro/rcp_exact.hip compares all 2^32 bit patterns against the IEEE division on
+    // gfx950: the only differences are denormal x, x >= 2^126 and infinities), 3 instructions instead of ~10.  |d| is at
+    // least 2^-23 here; components of 2^126 and more (and infinities) take the IEEE division.
+    const float ax = fabsf(dx), ay = fabsf(dy), az = fabsf(dz);
+    if (!(fmaxf(fmaxf(ax, ay), az) < 0x1p126f)) {
+        r.tcx = -1.0f / ax; r.tcy = -1.0f / ay; r.tcz = -1.0f / az;
+    } else {
+        r.tcx = -exact_rcp(ax); r.tcy = -exact_rcp(ay); r.tcz = -exact_rcp(az);
+    }
     r.tox = ox * r.tcx; r.toy = oy * r.tcy; r.toz = oz * r.tcz;
     r.mirror = 7u;
     if (dx > 0.0f) { r.mirror ^= 1u; r.tox = 3.0f * r.tcx - r.tox; }

@@ -17,6 +17,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see build.py).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 #include "../../include/vrc.h"
 #include "vrc_device.h"
@@ -840,8 +841,103 @@ __device__ __forceinline__ uint32_t probe_wave_max(uint32_t v)
 #define VRC_PROBE_WALK(r, k)
 #endif
 
-extern "C" __global__ void __launch_bounds__(VRC_RENDER_BLOCK, VRC_SYNC_MIN_WAVES)
-k_render_sync(const FrameArgs a)
+// raycaster.hpp:169-207 getGlobalIllumination for one pixel-sample (+ the nested second bounce of the extension): GI
+// ray from the point (bp, bn), cast with LOD coefficient 0.5; if it hits, a shadow ray from the GI hit towards the
+// light.  Called by all lanes of a wave whose pixel-sample has a primary hit (`in exec`); the two walks are wave-wide.
+template <bool ONE_BOUNCE>   // true: gi_bounces == 1 is known (the reference's semantics), the chain is straight-line code
+__device__ __forceinline__ float gi_chain(const uint2* __restrict__ nodes, uint2* stk, const uint2 root, const int depth,
+                                          const float n_normalizer, const float lx, const float ly, const float lz,
+                                          const uint32_t gi_bounces_rt, const uint32_t seed, const uint32_t fr, const uint32_t pix,
+                                          float base_px, float base_py, float base_pz, float base_nx, float base_ny, float base_nz,
+                                          uint32_t& n_rays, uint32_t& n_steps)
+{
+    const uint32_t gi_bounces = ONE_BOUNCE ? 1u : gi_bounces_rt;
+    Ray r;
+    bool active;
+    float ox, oy, oz, dx, dy, dz;
+    float acc[2] = {0.0f, 0.0f}, dgi[2] = {0.0f, 0.0f};
+    uint32_t draw = 2u, level = 0u;
+    bool chain = true;
+    while (chain) {
+        ox = base_px + base_nx * n_normalizer;                           // :174
+        oy = base_py + base_ny * n_normalizer;
+        oz = base_pz + base_nz * n_normalizer;
+        const float c1 = get_rand(counter_rand(seed, fr, pix, draw), -1000.0f, 1000.0f);
+        const float c2 = get_rand(counter_rand(seed, fr, pix, draw + 1u), -1000.0f, 1000.0f);
+        draw += 2u;
+        float qx = 0.0f, qy = 0.0f, qz = 0.0f;
+        if (base_nx != 0.0f)      { qy = c1; qz = c2; }
+        else if (base_ny != 0.0f) { qx = c1; qz = c2; }
+        else if (base_nz != 0.0f) { qx = c1; qy = c2; }
+        dx = (base_nx + qx) * n_normalizer;                              // :192
+        dy = (base_ny + qy) * n_normalizer;
+        dz = (base_nz + qz) * n_normalizer;
+        normalize3(dx, dy, dz);
+        const float dot_gi = dot3(dx, dy, dz, base_nx, base_ny, base_nz);   // :193
+        if (level == 0u) dgi[0] = dot_gi; else dgi[1] = dot_gi;
+        active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
+        ray_run<VRC_RENDER_BLOCK, 1>(r, active, nodes, stk, depth, 0.5f, 0.0f);   // :194
+        n_rays += 1u; n_steps += r.complexity;
+        Hit g;
+        ray_finish(r, depth, ox, oy, oz, dx, dy, dz, g);
+        chain = false;
+        if (g.hit) {                                                     // :195-203
+            ox = g.px + g.nx * n_normalizer;
+            oy = g.py + g.ny * n_normalizer;
+            oz = g.pz + g.nz * n_normalizer;
+            dx = lx - ox; dy = ly - oy; dz = lz - oz;
+            normalize3(dx, dy, dz);
+            const float dotl = dot3(g.nx, g.ny, g.nz, dx, dy, dz);         // :200
+            const float contrib = 1000000.0f * smin(0.5f, smax(0.0f, dotl) * dot_gi);   // :201
+            active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
+            ray_run<VRC_RENDER_BLOCK, 1>(r, active, nodes, stk, depth, 0.5f, 0.0f);   // :198
+            n_rays += 1u; n_steps += r.complexity;
+            if (!r.kind) { if (level == 0u) acc[0] += contrib; else acc[1] += contrib; }
+            if (level + 1u < gi_bounces) {
+                base_px = g.px; base_py = g.py; base_pz = g.pz;
+                base_nx = g.nx; base_ny = g.ny; base_nz = g.nz;
+                level += 1u;
+                chain = true;
+            }
+        }
+    }
+    // :206, innermost level first: gi = max(0, acc0 [+ dot_gi0 * max(0, acc1)])
+    if (level == 0u) return smax(0.0f, acc[0] / 1.0f);
+    acc[0] += dgi[0] * smax(0.0f, acc[1] / 1.0f);
+    return smax(0.0f, acc[0] / 1.0f);
+}
+
+// sink of one pixel-sample, raycaster.hpp:77-91: sum in registers (sample mode; one accumulator update per unit) or
+// the 0.4 / 0.6 temporal blend into render_image
+__device__ __forceinline__ void sink_sample(const FrameArgs& a, const uint32_t pix, const uint32_t color,
+                                            uint32_t& acc_r, uint32_t& acc_g, uint32_t& acc_b)
+{
+    if (a.p.use_samples) { acc_r += color & 0xffu; acc_g += (color >> 8) & 0xffu; acc_b += (color >> 16) & 0xffu; }
+    else {
+        uint32_t old = reinterpret_cast<uint32_t*>(a.image)[pix];
+        const uint32_t alpha = old & 0xff000000u;
+        old = color_mult(old & 0xffffffu, 0.4f);
+        const uint32_t nw = color_mult(color, 1.0f - 0.4f);
+        reinterpret_cast<uint32_t*>(a.image)[pix] = color_add_sat(old, nw) | alpha;
+    }
+}
+
+// raycaster.hpp:209-240: albedo of a primary hit from the two 16 x 16 tables staged in LDS
+__device__ __forceinline__ uint32_t albedo_of(const uint8_t* tex, const Hit& h)
+{
+    const uint8_t* img = (h.ny != 0.0f) ? tex : tex + 768;
+    const float tu = clampf_(h.u, 0.0f, 1.0f), tv = clampf_(h.v, 0.0f, 1.0f);
+    uint32_t idx = (uint32_t)(16.0f * tu) + (uint32_t)(16.0f * tv) * 16u;
+    idx = min(idx, 255u);
+    return (uint32_t)img[idx * 3] | ((uint32_t)img[idx * 3 + 1] << 8) | ((uint32_t)img[idx * 3 + 2] << 16);
+}
+
+// PINHOLE: the camera has aperture exactly +0 (the reference's default) -- decided by the host, see vrc_render_frame.
+// Then a pixel's camera ray is the same for every sample, and so are its primary hit, albedo and shadow ray(s): a work
+// unit sets them up ONCE and walks them once per sample of the unit (every ray the reference casts is still walked and
+// counted; only the identical arithmetic around the walks is not repeated).  The per-sample work is the GI pair.
+template <bool PINHOLE, bool ONE_BOUNCE>
+__device__ __forceinline__ void render_sync_body(const FrameArgs& a)
 {
     extern __shared__ uint2 lds_dyn[];   // [depth-1][256] stack | 1536 B textures
     uint2* stk = lds_dyn + threadIdx.x;
@@ -867,11 +963,7 @@ k_render_sync(const FrameArgs a)
     const uint32_t tiles_per_row = checker ? (W + 15u) / 16u : (W + 7u) / 8u;
     const uint32_t n_tiles = a.n_items >> 6;
     const bool sharded = a.p.row_block && a.p.shard_count > 1u;
-    // Pinhole camera (aperture exactly +0, the reference's default): rand_vec = 0 * getRand() is +-0, which changes
-    // neither focal_point - rand_vec (focal_point.x / .y are never -0 when focal_length >= 1e-30: lens.x / .y are +0
-    // or non-zero, camera_controller.hpp:36-42) nor, after the `+ 1`, the origin -- so the two lens draws and the
-    // products with them are skipped.  Any other aperture or focal_length takes the general path.
-    const bool pinhole = f2u(a.cam.aperture) == 0u && a.cam.focal_length >= 1e-30f && a.cam.focal_length < __builtin_inff();
+    constexpr bool pinhole = PINHOLE;     // see launch_render for the host's predicate
     // Work unit = (tile, chunk of `sample_chunk` samples).  With few tiles per GPU (multi-GPU shards)
     // the host splits a pixel's samples over several units so every wave still gets several units;
     // the accumulators are then updated with integer atomics (exact, order-independent).
@@ -950,47 +1042,41 @@ k_render_sync(const FrameArgs a)
         const uint32_t pix = px_y * W + px_x;
         uint32_t acc_r = 0u, acc_g = 0u, acc_b = 0u;
 
-        for (uint32_t sample = s_begin; sample < s_end; ++sample) {
-            const uint32_t fr = a.p.frame_index + sample;
-            uint32_t color = 0u;                                                 // ColorResult: Black
-#ifdef VRC_PROBE
-            uint32_t probe_c0 = 0u, probe_c1 = 0u, probe_c2 = 0u, probe_c3 = 0u;
-#endif
+        if constexpr (PINHOLE) {
+            // ---- the stages that do not depend on the sample: set up once, walked once per sample of the unit
+            const uint32_t n_samples = s_end - s_begin;
+            bool hit = false;
+            uint32_t albedo = 0u;
+            float light_intensity = 0.0f;
+            float hpx = 0.0f, hpy = 0.0f, hpz = 0.0f, hnx = 0.0f, hny = 0.0f, hnz = 0.0f;
             if (valid) {
-                // R0: main.cpp:133,145-149; camera_controller.hpp:34-54
+                // R0: main.cpp:133,145-149; camera_controller.hpp:34-54 with rand_vec = +-0 (see PINHOLE above)
                 const float aspect_ratio = (float)W / (float)H;
                 const float lens_x = (float)px_x / (float)H - aspect_ratio * 0.5f;
                 const float lens_y = (float)px_y / (float)H - 0.5f;
                 float sx = lens_x, sy = lens_y, sz = a.cam.fov;
                 normalize3(sx, sy, sz);
-                const float fx = sx * a.cam.focal_length, fy = sy * a.cam.focal_length, fz = sz * a.cam.focal_length;
-                float vx = fx, vy = fy, vz = fz;
-                float wx = 0.0f, wy = 0.0f, wz = 0.0f;
+                float vx = sx * a.cam.focal_length, vy = sy * a.cam.focal_length, vz = sz * a.cam.focal_length;
                 const float* m = a.cam.rot;
-                if (!pinhole) {
-                    const float r0 = get_rand(counter_rand(a.p.seed, fr, pix, 0u), -0.5f, 0.5f);
-                    const float r1 = get_rand(counter_rand(a.p.seed, fr, pix, 1u), -0.5f, 0.5f);
-                    const float rvx = a.cam.aperture * r0, rvy = a.cam.aperture * r1, rvz = a.cam.aperture * 0.0f;
-                    vx = fx - rvx; vy = fy - rvy; vz = fz - rvz;
-                    wx = (m[0] * rvx + m[1] * rvy) + m[2] * rvz;
-                    wy = (m[3] * rvx + m[4] * rvy) + m[5] * rvz;
-                    wz = (m[6] * rvx + m[7] * rvy) + m[8] * rvz;
-                }
                 normalize3(vx, vy, vz);
                 float dx = (m[0] * vx + m[1] * vy) + m[2] * vz;
                 float dy = (m[3] * vx + m[4] * vy) + m[5] * vz;
                 float dz = (m[6] * vx + m[7] * vy) + m[8] * vz;
-                float ox = (a.cam.position[0] + wx) * inv_size + 1.0f;
-                float oy = (a.cam.position[1] + wy) * inv_size + 1.0f;
-                float oz = (a.cam.position[2] + wz) * inv_size + 1.0f;
-                Ray r;
-                bool active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
-                ray_run<VRC_RENDER_BLOCK, 0>(r, active, nodes, stk, depth, 0.0f, 0.0f);
-                n_rays += 1u; n_steps += r.complexity; VRC_PROBE_WALK(r, 0)
+                float ox = (a.cam.position[0] + 0.0f) * inv_size + 1.0f;
+                float oy = (a.cam.position[1] + 0.0f) * inv_size + 1.0f;
+                float oz = (a.cam.position[2] + 0.0f) * inv_size + 1.0f;
+                Ray r0, r;
+                bool active = ray_setup(r0, root, ox, oy, oz, dx, dy, dz);
+                r = r0;
+                for (uint32_t k = 0; k < n_samples; ++k) {                          // raycaster.hpp:131, once per sample
+                    r = r0;
+                    ray_run<VRC_RENDER_BLOCK, 0>(r, active, nodes, stk, depth, 0.0f, 0.0f);
+                    n_rays += 1u; n_steps += r.complexity;
+                }
                 Hit h;
-                ray_finish(r, depth, ox, oy, oz, dx, dy, dz, h);                   // raycaster.hpp:131
+                ray_finish(r, depth, ox, oy, oz, dx, dy, dz, h);
 #ifndef VRC_PROBE
-                if (a.prim && sample == 0u) {
+                if (a.prim && s_begin == 0u) {
                     uint4* o = reinterpret_cast<uint4*>(a.prim + pix);
                     o[0] = make_uint4(f2u(h.px), f2u(h.py), f2u(h.pz), f2u(h.nx));
                     o[1] = make_uint4(f2u(h.ny), f2u(h.nz), f2u(h.u), f2u(h.v));
@@ -998,97 +1084,120 @@ k_render_sync(const FrameArgs a)
                 }
 #endif
                 if (h.hit) {
-                    n_hits += 1u;
-                    // raycaster.hpp:209-240 albedo
-                    const uint8_t* img = (h.ny != 0.0f) ? tex : tex + 768;
-                    const float tu = clampf_(h.u, 0.0f, 1.0f), tv = clampf_(h.v, 0.0f, 1.0f);
-                    uint32_t idx = (uint32_t)(16.0f * tu) + (uint32_t)(16.0f * tv) * 16u;
-                    idx = min(idx, 255u);
-                    const uint32_t albedo = (uint32_t)img[idx * 3] | ((uint32_t)img[idx * 3 + 1] << 8) | ((uint32_t)img[idx * 3 + 2] << 16);
+                    hit = true;
+                    n_hits += n_samples;
+                    albedo = albedo_of(tex, h);                                     // raycaster.hpp:141-145
+                    hpx = h.px; hpy = h.py; hpz = h.pz; hnx = h.nx; hny = h.ny; hnz = h.nz;
                     // raycaster.hpp:139,150-158 shadow ray(s): the reference re-casts the identical ray
-                    float light_intensity = 0.0f;
                     ox = h.px + h.nx * inv_size * 0.001f;
                     oy = h.py + h.ny * inv_size * 0.001f;
                     oz = h.pz + h.nz * inv_size * 0.001f;
-                    for (uint32_t i = shadow_samples; i--;) {
-                        dx = lx - ox; dy = ly - oy; dz = lz - oz;
-                        normalize3(dx, dy, dz);
-                        const float lit = smax(0.0f, dot3(dx, dy, dz, h.nx, h.ny, h.nz));       // :156
-                        active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
+                    dx = lx - ox; dy = ly - oy; dz = lz - oz;
+                    normalize3(dx, dy, dz);
+                    const float lit = smax(0.0f, dot3(dx, dy, dz, h.nx, h.ny, h.nz));           // :156
+                    active = ray_setup(r0, root, ox, oy, oz, dx, dy, dz);
+                    for (uint32_t k = n_samples * shadow_samples; k--;) {
+                        r = r0;
                         ray_run<VRC_RENDER_BLOCK, 0>(r, active, nodes, stk, depth, 0.0f, 0.0f);
-                        n_rays += 1u; n_steps += r.complexity; VRC_PROBE_WALK(r, 1)
-                        if (!r.kind) light_intensity = lit;                                  // :155-157
+                        n_rays += 1u; n_steps += r.complexity;
                     }
-                    // raycaster.hpp:161,169-207 GI (+ the nested second bounce of the extension)
-                    float gi_intensity = 0.0f;
-                    if (a.p.use_gi) {
-                        float base_px = h.px, base_py = h.py, base_pz = h.pz, base_nx = h.nx, base_ny = h.ny, base_nz = h.nz;
-                        float acc[2] = {0.0f, 0.0f}, dgi[2] = {0.0f, 0.0f};
-                        uint32_t draw = 2u, level = 0u;
-                        bool chain = true;
-                        while (chain) {
-                            ox = base_px + base_nx * n_normalizer;                           // :174
-                            oy = base_py + base_ny * n_normalizer;
-                            oz = base_pz + base_nz * n_normalizer;
-                            const float c1 = get_rand(counter_rand(a.p.seed, fr, pix, draw), -1000.0f, 1000.0f);
-                            const float c2 = get_rand(counter_rand(a.p.seed, fr, pix, draw + 1u), -1000.0f, 1000.0f);
-                            draw += 2u;
-                            float qx = 0.0f, qy = 0.0f, qz = 0.0f;
-                            if (base_nx != 0.0f)      { qy = c1; qz = c2; }
-                            else if (base_ny != 0.0f) { qx = c1; qz = c2; }
-                            else if (base_nz != 0.0f) { qx = c1; qy = c2; }
-                            dx = (base_nx + qx) * n_normalizer;                              // :192
-                            dy = (base_ny + qy) * n_normalizer;
-                            dz = (base_nz + qz) * n_normalizer;
-                            normalize3(dx, dy, dz);
-                            const float dot_gi = dot3(dx, dy, dz, base_nx, base_ny, base_nz);   // :193
-                            if (level == 0u) dgi[0] = dot_gi; else dgi[1] = dot_gi;
-                            active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
-                            ray_run<VRC_RENDER_BLOCK, 1>(r, active, nodes, stk, depth, 0.5f, 0.0f);   // :194
-                            n_rays += 1u; n_steps += r.complexity; VRC_PROBE_WALK(r, 2)
-                            Hit g;
-                            ray_finish(r, depth, ox, oy, oz, dx, dy, dz, g);
-                            chain = false;
-                            if (g.hit) {                                                     // :195-203
-                                ox = g.px + g.nx * n_normalizer;
-                                oy = g.py + g.ny * n_normalizer;
-                                oz = g.pz + g.nz * n_normalizer;
-                                dx = lx - ox; dy = ly - oy; dz = lz - oz;
-                                normalize3(dx, dy, dz);
-                                const float dotl = dot3(g.nx, g.ny, g.nz, dx, dy, dz);         // :200
-                                const float contrib = 1000000.0f * smin(0.5f, smax(0.0f, dotl) * dot_gi);   // :201
-                                active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
-                                ray_run<VRC_RENDER_BLOCK, 1>(r, active, nodes, stk, depth, 0.5f, 0.0f);   // :198
-                                n_rays += 1u; n_steps += r.complexity; VRC_PROBE_WALK(r, 3)
-                                if (!r.kind) { if (level == 0u) acc[0] += contrib; else acc[1] += contrib; }
-                                if (level + 1u < gi_bounces) {
-                                    base_px = g.px; base_py = g.py; base_pz = g.pz;
-                                    base_nx = g.nx; base_ny = g.ny; base_nz = g.nz;
-                                    level += 1u;
-                                    chain = true;
-                                }
-                            }
-                        }
-                        // :206, innermost level first: gi = max(0, acc0 [+ dot_gi0 * max(0, acc1)])
-                        if (level == 0u) gi_intensity = smax(0.0f, acc[0] / 1.0f);
-                        else { acc[0] += dgi[0] * smax(0.0f, acc[1] / 1.0f); gi_intensity = smax(0.0f, acc[0] / 1.0f); }
-                    }
-                    color = color_mult(albedo, smin(1.0f, smax(0.0f, light_intensity + gi_intensity)));   // :163
-                }
-                // sink: raycaster.hpp:77-91
-                n_pix += 1u;
-                if (a.p.use_samples) { acc_r += color & 0xffu; acc_g += (color >> 8) & 0xffu; acc_b += (color >> 16) & 0xffu; }
-                else {
-                    uint32_t old = reinterpret_cast<uint32_t*>(a.image)[pix];
-                    const uint32_t alpha = old & 0xff000000u;
-                    old = color_mult(old & 0xffffffu, 0.4f);
-                    const uint32_t nw = color_mult(color, 1.0f - 0.4f);
-                    reinterpret_cast<uint32_t*>(a.image)[pix] = color_add_sat(old, nw) | alpha;
+                    if (!r.kind) light_intensity = lit;                                      // :155-157
                 }
             }
+            // ---- per sample: the GI pair (raycaster.hpp:161,169-207), shading, sink
+            for (uint32_t sample = s_begin; sample < s_end; ++sample) {
+                if (valid) {
+                    uint32_t color = 0u;                                             // ColorResult: Black
+                    if (hit) {
+                        float gi_intensity = 0.0f;
+                        if (a.p.use_gi)
+                            gi_intensity = gi_chain<ONE_BOUNCE>(nodes, stk, root, depth, n_normalizer, lx, ly, lz, gi_bounces, a.p.seed,
+                                                    a.p.frame_index + sample, pix, hpx, hpy, hpz, hnx, hny, hnz, n_rays, n_steps);
+                        color = color_mult(albedo, smin(1.0f, smax(0.0f, light_intensity + gi_intensity)));   // :163
+                    }
+                    n_pix += 1u;
+                    sink_sample(a, pix, color, acc_r, acc_g, acc_b);
+                }
+            }
+        } else {
+            for (uint32_t sample = s_begin; sample < s_end; ++sample) {
+                const uint32_t fr = a.p.frame_index + sample;
+                uint32_t color = 0u;                                                 // ColorResult: Black
 #ifdef VRC_PROBE
-            probe_iters += probe_wave_max(probe_c0) + probe_wave_max(probe_c1) + probe_wave_max(probe_c2) + probe_wave_max(probe_c3);
+                uint32_t probe_c0 = 0u, probe_c1 = 0u, probe_c2 = 0u, probe_c3 = 0u;
 #endif
+                if (valid) {
+                    // R0: main.cpp:133,145-149; camera_controller.hpp:34-54
+                    const float aspect_ratio = (float)W / (float)H;
+                    const float lens_x = (float)px_x / (float)H - aspect_ratio * 0.5f;
+                    const float lens_y = (float)px_y / (float)H - 0.5f;
+                    float sx = lens_x, sy = lens_y, sz = a.cam.fov;
+                    normalize3(sx, sy, sz);
+                    const float fx = sx * a.cam.focal_length, fy = sy * a.cam.focal_length, fz = sz * a.cam.focal_length;
+                    float vx = fx, vy = fy, vz = fz;
+                    float wx = 0.0f, wy = 0.0f, wz = 0.0f;
+                    const float* m = a.cam.rot;
+                    if (!pinhole) {
+                        const float r0 = get_rand(counter_rand(a.p.seed, fr, pix, 0u), -0.5f, 0.5f);
+                        const float r1 = get_rand(counter_rand(a.p.seed, fr, pix, 1u), -0.5f, 0.5f);
+                        const float rvx = a.cam.aperture * r0, rvy = a.cam.aperture * r1, rvz = a.cam.aperture * 0.0f;
+                        vx = fx - rvx; vy = fy - rvy; vz = fz - rvz;
+                        wx = (m[0] * rvx + m[1] * rvy) + m[2] * rvz;
+                        wy = (m[3] * rvx + m[4] * rvy) + m[5] * rvz;
+                        wz = (m[6] * rvx + m[7] * rvy) + m[8] * rvz;
+                    }
+                    normalize3(vx, vy, vz);
+                    float dx = (m[0] * vx + m[1] * vy) + m[2] * vz;
+                    float dy = (m[3] * vx + m[4] * vy) + m[5] * vz;
+                    float dz = (m[6] * vx + m[7] * vy) + m[8] * vz;
+                    float ox = (a.cam.position[0] + wx) * inv_size + 1.0f;
+                    float oy = (a.cam.position[1] + wy) * inv_size + 1.0f;
+                    float oz = (a.cam.position[2] + wz) * inv_size + 1.0f;
+                    Ray r;
+                    bool active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
+                    ray_run<VRC_RENDER_BLOCK, 0>(r, active, nodes, stk, depth, 0.0f, 0.0f);
+                    n_rays += 1u; n_steps += r.complexity; VRC_PROBE_WALK(r, 0)
+                    Hit h;
+                    ray_finish(r, depth, ox, oy, oz, dx, dy, dz, h);                   // raycaster.hpp:131
+#ifndef VRC_PROBE
+                    if (a.prim && sample == 0u) {
+                        uint4* o = reinterpret_cast<uint4*>(a.prim + pix);
+                        o[0] = make_uint4(f2u(h.px), f2u(h.py), f2u(h.pz), f2u(h.nx));
+                        o[1] = make_uint4(f2u(h.ny), f2u(h.nz), f2u(h.u), f2u(h.v));
+                        o[2] = make_uint4(h.hit, h.node, f2u(h.distance), h.complexity);
+                    }
+#endif
+                    if (h.hit) {
+                        n_hits += 1u;
+                        const uint32_t albedo = albedo_of(tex, h);                             // raycaster.hpp:141-145
+                        // raycaster.hpp:139,150-158 shadow ray(s): the reference re-casts the identical ray
+                        float light_intensity = 0.0f;
+                        ox = h.px + h.nx * inv_size * 0.001f;
+                        oy = h.py + h.ny * inv_size * 0.001f;
+                        oz = h.pz + h.nz * inv_size * 0.001f;
+                        for (uint32_t i = shadow_samples; i--;) {
+                            dx = lx - ox; dy = ly - oy; dz = lz - oz;
+                            normalize3(dx, dy, dz);
+                            const float lit = smax(0.0f, dot3(dx, dy, dz, h.nx, h.ny, h.nz));       // :156
+                            active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
+                            ray_run<VRC_RENDER_BLOCK, 0>(r, active, nodes, stk, depth, 0.0f, 0.0f);
+                            n_rays += 1u; n_steps += r.complexity; VRC_PROBE_WALK(r, 1)
+                            if (!r.kind) light_intensity = lit;                                  // :155-157
+                        }
+                        // raycaster.hpp:161,169-207 GI (+ the nested second bounce of the extension)
+                        float gi_intensity = 0.0f;
+                        if (a.p.use_gi)
+                            gi_intensity = gi_chain<ONE_BOUNCE>(nodes, stk, root, depth, n_normalizer, lx, ly, lz, gi_bounces, a.p.seed, fr, pix,
+                                                    h.px, h.py, h.pz, h.nx, h.ny, h.nz, n_rays, n_steps);
+                        color = color_mult(albedo, smin(1.0f, smax(0.0f, light_intensity + gi_intensity)));   // :163
+                    }
+                    n_pix += 1u;
+                    sink_sample(a, pix, color, acc_r, acc_g, acc_b);
+                }
+#ifdef VRC_PROBE
+                probe_iters += probe_wave_max(probe_c0) + probe_wave_max(probe_c1) + probe_wave_max(probe_c2) + probe_wave_max(probe_c3);
+#endif
+            }
         }
         if (valid && a.p.use_samples) {                                              // raycaster.hpp:87-90
             if (chunks_per_tile == 1u) {
@@ -1132,6 +1241,26 @@ k_render_sync(const FrameArgs a)
         atomicAdd(reinterpret_cast<unsigned long long*>(slot + 2), (unsigned long long)s_hits);
         atomicAdd(reinterpret_cast<unsigned long long*>(slot + 3), (unsigned long long)s_pix);
     }
+}
+
+// k_render_sync: any camera, any gi_bounces.  k_render_sync_pinhole: aperture +0 and the reference's one indirect
+// bounce -- the configuration the reference ships with and BASELINE's metric is quoted on.
+extern "C" __global__ void __launch_bounds__(VRC_RENDER_BLOCK, VRC_SYNC_MIN_WAVES)
+k_render_sync(const FrameArgs a)
+{
+    render_sync_body<false, false>(a);
+}
+
+extern "C" __global__ void __launch_bounds__(VRC_RENDER_BLOCK, VRC_SYNC_MIN_WAVES)
+k_render_sync_pinhole(const FrameArgs a)
+{
+    render_sync_body<true, true>(a);
+}
+
+extern "C" __global__ void __launch_bounds__(VRC_RENDER_BLOCK, VRC_SYNC_MIN_WAVES)
+k_render_sync_pinhole2(const FrameArgs a)
+{
+    render_sync_body<true, false>(a);
 }
 
 // ---------------------------------------------------------------------------
@@ -1287,7 +1416,19 @@ hipError_t launch_render(const FrameArgs& a, uint32_t grid_blocks, int kernel, h
         hipLaunchKernelGGL(k_render_tile, dim3(grid_blocks), dim3(VRC_RENDER_BLOCK), lds, st, a);
     } else {
         const size_t lds = (size_t)(a.depth - 1) * VRC_RENDER_BLOCK * sizeof(uint2) + 1536;
-        hipLaunchKernelGGL(k_render_sync, dim3(grid_blocks), dim3(VRC_RENDER_BLOCK), lds, st, a);
+        // Pinhole camera (aperture exactly +0, the reference's default): rand_vec = 0 * getRand() is +-0, which changes
+        // neither focal_point - rand_vec (focal_point.x / .y are never -0 when focal_length >= 1e-30: lens.x / .y are +0
+        // or non-zero, camera_controller.hpp:36-42) nor, after the `+ 1`, the origin -- so the two lens draws and the
+        // products with them are skipped.  Any other aperture or focal_length takes the general kernel.
+        uint32_t ap_bits;
+        memcpy(&ap_bits, &a.cam.aperture, 4);
+        bool pinhole = ap_bits == 0u && a.cam.focal_length >= 1e-30f && a.cam.focal_length < __builtin_inff();
+#ifdef VRC_NO_PINHOLE_KERNEL   // A/B builds only
+        pinhole = false;
+#endif
+        if (pinhole && a.p.gi_bounces <= 1u) hipLaunchKernelGGL(k_render_sync_pinhole, dim3(grid_blocks), dim3(VRC_RENDER_BLOCK), lds, st, a);
+        else if (pinhole) hipLaunchKernelGGL(k_render_sync_pinhole2, dim3(grid_blocks), dim3(VRC_RENDER_BLOCK), lds, st, a);
+        else hipLaunchKernelGGL(k_render_sync, dim3(grid_blocks), dim3(VRC_RENDER_BLOCK), lds, st, a);
     }
     return hipGetLastError();
 }
