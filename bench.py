@@ -272,7 +272,7 @@ def main():
     n_slots = 2 if F == 1 else F + 2
 
     ev_pairs = []
-    state = {"i": 0, "pending": [None] * n_slots, "last_slot": 0}
+    state = {"i": 0, "pending": [None] * n_slots, "last_slot": 0, "gather": args.gather}
 
     def finish_gather(slot):
         """wait (on the current stream) for the slot's outstanding all-gather and scatter it into the slot's frame"""
@@ -282,7 +282,7 @@ def main():
         if work != "sync":
             work.wait()                                        # current stream waits for the collective
         state["pending"][slot] = None
-        if args.gather == "root" and rank != 0:
+        if state["gather"] == "root" and rank != 0:
             return                                             # only the presenting rank composes the frame
         vrc.capi.check(L.vrc_unpack_shards(vrc.capi.ptr(gathered[slot].data_ptr()), W, H, ROW_BLOCK, world,
                                            vrc.capi.ptr(full[slot].data_ptr()),
@@ -314,7 +314,7 @@ def main():
                     # RCCL over xGMI: RGBA8 row-block shards; enqueued behind the resolve, runs beside the next render.
                     # --gather all: all-gather; --gather root: rank 0 receives every shard straight into its place of
                     # the [shard][slot] buffer (one direct hop per peer), the other ranks only send
-                    state["pending"][slot] = vdist.exchange_shards(mine[slot], gathered[slot], world, rank, args.gather, async_op=True)
+                    state["pending"][slot] = vdist.exchange_shards(mine[slot], gathered[slot], world, rank, state["gather"], async_op=True)
                 else:
                     ts.synchronize()
                     parts = [torch.empty_like(mine[slot]) for _ in range(world)]
@@ -387,6 +387,37 @@ def main():
         ref.samples_to_image(stream)
         torch.cuda.synchronize()
         verified = bool(np.array_equal(full[state["last_slot"]].cpu().numpy().reshape(H, W, 4), ref.readImage(stream)))
+
+    # extra, N > 1 on RCCL: the same frames with the OTHER exchange form (all-gather <-> gather to rank 0), so that one
+    # driver run records both (not part of `value`)
+    other = None
+    if dist_on and backend == "nccl":
+        state["gather"] = "root" if args.gather == "all" else "all"
+        n_o = max(5, min(args.steps, 30))
+        for _ in range(3):
+            step(False)
+        drain()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t_o = time.perf_counter()
+        for _ in range(n_o):
+            step(False)
+        drain()
+        dist.barrier()
+        torch.cuda.synchronize()
+        dt_o = torch.tensor([time.perf_counter() - t_o], dtype=torch.float64, device="cuda")
+        dist.all_reduce(dt_o, op=dist.ReduceOp.MAX)
+        ok_o = None
+        if rank == 0:
+            ref = make_renderer()
+            ref.frame_index = (state["i"] - 1) * spp
+            ref.renderFrame(cam, spp=spp, stream=stream)
+            ref.samples_to_image(stream)
+            torch.cuda.synchronize()
+            ok_o = bool(np.array_equal(full[state["last_slot"]].cpu().numpy().reshape(H, W, 4), ref.readImage(stream)))
+        other = {"exchange": "gather to rank 0" if state["gather"] == "root" else "all-gather", "steps": n_o,
+                 "ms_per_step": round(float(dt_o.item()) / n_o * 1e3, 4), "gathered_frame_equals_unsharded": ok_o}
+        state["gather"] = args.gather
 
     # untimed extra, N = 1 only: BASELINE config 3's text says "GI 2 bounces"; the reference has ONE indirect bounce
     # (RayContext::gi_bounce is never read), which is what `value` measures -- the 2-bounce EXTENSION
@@ -469,6 +500,9 @@ def main():
                        "gathered_frame_equals_unsharded": verified},
             "roofline": roof,
         }
+        if other is not None:
+            other["value"] = round(rays / args.steps / (other["ms_per_step"] * 1e-3) / 1e6, 2)
+            extras["other_exchange_form"] = other
         if extras:
             out["extra"] = extras
         if world == 1 and not args.no_cpu_baseline:

@@ -54,7 +54,9 @@ Tuning g_tuning;
 std::mutex g_tuning_mu;
 
 constexpr uint32_t VRC_MAX_SPP = 65536;          // per call; the u32 accumulators hold 255 * 16.8 M samples in total
-constexpr uint32_t VRC_MAX_QUEUE_CHUNK = 1u << 20;
+// queue chunk of k_render: the head counter overshoots n_items by at most (waves in flight) x chunk after the queue runs dry;
+// 8192 waves x 2^16 + 2^31 pixels stays below 2^32
+constexpr uint32_t VRC_MAX_QUEUE_CHUNK = 1u << 16;
 
 int apply_sample_chunk(Tuning& t, uint32_t samples_per_unit)
 {

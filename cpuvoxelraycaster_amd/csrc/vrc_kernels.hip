@@ -386,7 +386,7 @@ k_render(const FrameArgs a)
                     base = __builtin_amdgcn_readfirstlane(base);
                     if (base >= a.n_items) { exhausted = true; break; }
                     cur = base;
-                    end = min(base + a.chunk, a.n_items);
+                    end = base + min(a.chunk, a.n_items - base);   // no wrap: base < n_items
                 }
                 const uint32_t avail = end - cur;
                 const uint32_t cnt = (uint32_t)__popcll(mask);

@@ -85,7 +85,7 @@ def test_frame_limits_are_errors(built, heights, textures):
     with pytest.raises(vrc.VrcError):
         rc.setSampleChunk(70000)
     with pytest.raises(vrc.VrcError):
-        rc.setTuning(0, 0, 1 << 21)
+        rc.setTuning(0, 0, (1 << 16) + 1)
     with pytest.raises(vrc.VrcError):
         rc.setKernel(3)
     rc.renderFrame(cam, spp=2)                          # still usable
