@@ -10,15 +10,18 @@ frame kernel, the sample resolve, and -- for N > 1 -- the row-block shard pack,
 the RCCL all-gather of the RGBA8 framebuffer and the unpack.  rays = traversals
 actually executed (counted by the kernel, equal to the oracle's count).
 
-Frames are independent.  On one GPU they are issued on one stream, each after
-the other (`--inflight 1`: ms_per_step is a frame latency and a launch never
-shares the chip, which keeps the per-launch roofline clean).  On several GPUs a
-rank's shard is small and its launch is mostly tail -- the last work units finish
-at latency speed with most of the chip idle -- so there two renderers / streams
-alternate (`--inflight 2`) and the end of one launch overlaps the start of the
-next frame, just as the all-gather of frame i overlaps the renders after it;
-ms_per_step is then the steady-state frame period.  `config.frames_in_flight`
-says which was used.
+Frames are independent, and a launch of the persistent frame kernel is mostly
+tail at its end: the last work units finish at latency speed while most of the
+chip idles (~4 % of a 1080p frame on one GPU, more on a multi-GPU shard).  So two
+renderers / streams alternate by default (`--inflight 2`): the end of one launch
+overlaps the start of the next frame, just as the exchange of frame i overlaps
+the renders after it.  ms_per_step is then the steady-state frame PERIOD (all K
+frames are complete inside the timed region) and can be shorter than one
+kernel's duration, which `roofline.kernel_ms` reports from events on the launch
+streams; `config.frames_in_flight` says which was used.  At N = 1 the plain
+one-stream loop (`--inflight 1`: each frame starts when the previous one has
+ended, ms_per_step = a frame's latency) is measured right after the timed region
+and reported as `extra.one_frame_in_flight`.
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -181,7 +184,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inflight", type=int, default=0,
                     help="frames in flight per GPU (renderers / streams used round-robin); 1 = one stream, each frame starts "
-                         "when the previous one has ended; 0 = automatic: 1 on one GPU, 2 on several")
+                         "when the previous one has ended; 0 = default: 2")
     ap.add_argument("--gather", default="all", choices=["all", "root"],
                     help="N > 1: how the RGBA8 row-block shards meet: 'all' = RCCL all-gather (every rank ends up with the "
                          "frame), 'root' = RCCL gather to rank 0, the presenting rank (north_star / SURVEY 8e: 1/N of the "
@@ -260,7 +263,7 @@ def main():
     # one launch (its last work units finish at latency speed with most of the chip idle) overlaps the start of the
     # next frame's launch, like the all-gather of frame i overlaps the render of frame i + 1.  Frames stay independent
     # and complete in order; F = 1 is the plain one-stream loop.
-    F = args.inflight if args.inflight > 0 else (2 if dist_on else 1)
+    F = args.inflight if args.inflight > 0 else 2
 
     def make_renderer():
         r = vrc.RayCaster(svo, (W, H))
@@ -434,6 +437,32 @@ def main():
     # (RayContext::gi_bounce is never read), which is what `value` measures -- the 2-bounce EXTENSION
     # (recursive getGlobalIllumination at the GI hit, defined by the oracle) is reported beside it
     extras = {}
+    if rank == 0 and world == 1 and not dist_on and not args.no_extras and F > 1:
+        # the same frames one at a time on one stream: a frame's latency, and the kernel's duration when it has the chip alone
+        rc1 = make_renderer()
+        ts = tstreams[0]
+        n1 = max(10, min(args.steps, 50))
+        evs = []
+        with torch.cuda.stream(ts):
+            for i in range(3 + n1):
+                if i == 3:
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                rc1.frame_index = i * spp
+                ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ea.record(ts)
+                rc1.renderFrame(cam, spp=spp, stream=ts.cuda_stream)
+                eb.record(ts)
+                rc1.resolveShard(reset=True, stream=ts.cuda_stream)
+                if i >= 3:
+                    evs.append((ea, eb))
+            torch.cuda.synchronize()
+            dt1 = time.perf_counter() - t1
+        st1 = rc1.stats(stream=ts.cuda_stream)
+        extras["one_frame_in_flight"] = {
+            "ms_per_step": round(dt1 / n1 * 1e3, 4), "kernel_ms": round(sum(a.elapsed_time(b) for a, b in evs) / len(evs), 4),
+            "value": round(st1.rays / (3 + n1) * n1 / dt1 / 1e6, 2), "unit": "Mrays/s", "steps": n1,
+            "note": "--inflight 1: one stream, each frame starts when the previous one has ended"}
     if rank == 0 and world == 1 and not dist_on and not args.no_extras and args.config == "c3":
         rc2 = make_renderer()
         rc2.gi_bounces = 2
