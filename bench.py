@@ -502,7 +502,7 @@ def main():
         # passes recorded in profiles/traffic.json -- only when that record was taken on THIS tree's kernel sources
         # (the stage-synchronous kernel has a specialisation for the pinhole camera, see csrc/vrc_kernels.hip launch_render)
         pinhole = cam.aperture == 0.0 and math.copysign(1.0, cam.aperture) > 0 and 1e-30 <= cam.focal_length < float("inf")
-        sync_kernel_name = ("k_render_sync_pinhole" if cfg.get("gi_bounces", 1) <= 1 else "k_render_sync_pinhole2") if pinhole else "k_render_sync"
+        sync_kernel_name = ("k_render_sync_pinhole" if pinhole else "k_render_sync") + ("" if cfg.get("gi_bounces", 1) <= 1 else "2")
         rec, why = pmc_record(f"{args.config}_n{world}") if args.kernel == 2 else (None, "PMC record exists for k_render_sync only")
         traffic = rec["traffic_bytes"] if rec else None
         roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",

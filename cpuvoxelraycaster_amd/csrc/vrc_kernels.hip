@@ -1243,10 +1243,18 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
     }
 }
 
-// k_render_sync: any camera, any gi_bounces.  k_render_sync_pinhole: aperture +0 and the reference's one indirect
-// bounce -- the configuration the reference ships with and BASELINE's metric is quoted on.
+// k_render_sync: any camera, the reference's one indirect bounce (k_render_sync2: the 2-bounce extension).
+// k_render_sync_pinhole: aperture +0 and one bounce -- the configuration the reference ships with and BASELINE's metric
+// is quoted on (k_render_sync_pinhole2: with the extension).  The bounce count is a compile-time fact in the one-bounce
+// kernels: gi_chain is straight-line code there, which is worth a third of the register spills.
 extern "C" __global__ void __launch_bounds__(VRC_RENDER_BLOCK, VRC_SYNC_MIN_WAVES)
 k_render_sync(const FrameArgs a)
+{
+    render_sync_body<false, true>(a);
+}
+
+extern "C" __global__ void __launch_bounds__(VRC_RENDER_BLOCK, VRC_SYNC_MIN_WAVES)
+k_render_sync2(const FrameArgs a)
 {
     render_sync_body<false, false>(a);
 }
@@ -1428,7 +1436,8 @@ hipError_t launch_render(const FrameArgs& a, uint32_t grid_blocks, int kernel, h
 #endif
         if (pinhole && a.p.gi_bounces <= 1u) hipLaunchKernelGGL(k_render_sync_pinhole, dim3(grid_blocks), dim3(VRC_RENDER_BLOCK), lds, st, a);
         else if (pinhole) hipLaunchKernelGGL(k_render_sync_pinhole2, dim3(grid_blocks), dim3(VRC_RENDER_BLOCK), lds, st, a);
-        else hipLaunchKernelGGL(k_render_sync, dim3(grid_blocks), dim3(VRC_RENDER_BLOCK), lds, st, a);
+        else if (a.p.gi_bounces <= 1u) hipLaunchKernelGGL(k_render_sync, dim3(grid_blocks), dim3(VRC_RENDER_BLOCK), lds, st, a);
+        else hipLaunchKernelGGL(k_render_sync2, dim3(grid_blocks), dim3(VRC_RENDER_BLOCK), lds, st, a);
     }
     return hipGetLastError();
 }

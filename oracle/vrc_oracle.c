@@ -310,6 +310,12 @@ void orc_terrain_heights(int32_t size, int32_t seed, int32_t *height)
 #define ORC_MAX_DEPTH 16
 #define ORC_MAX_ITERATIONS 65536u
 
+/* Analysis hook (tools/path_schedule.py): when set, the walk appends one byte per loop iteration -- 0 descend,
+ * 1 advance, 2 advance + pop, 3 the iteration that ends in a leaf / LOD hit -- up to orc_optrace_cap bytes. */
+static __thread uint8_t *orc_optrace;
+static __thread uint32_t orc_optrace_cap;
+#define ORC_OP(code) do { if (orc_optrace && result->complexity <= orc_optrace_cap) orc_optrace[result->complexity - 1u] = (code); } while (0)
+
 void orc_cast_ray(const orc_lnode *raw_data, uint32_t depth,
                   const float org[3], const float dir[3],
                   float ray_size_coef, float ray_size_bias, orc_hit *result)
@@ -383,6 +389,7 @@ void orc_cast_ray(const orc_lnode *raw_data, uint32_t depth,
             /* :82-85 LOD cut */
             if (tc_max * ray_size_coef + ray_size_bias >= scale_f) {
                 hit_kind = 2u; hit_shift = child_shift;
+                ORC_OP(3);
                 break;
             }
             /* :86-88 */
@@ -393,6 +400,7 @@ void orc_cast_ray(const orc_lnode *raw_data, uint32_t depth,
                 const uint8_t leaf_mask = (uint8_t)(parent_ref.leaf_mask >> child_shift);
                 if (leaf_mask & 1u) {                         /* :92-95 */
                     hit_kind = 1u; hit_shift = child_shift;
+                    ORC_OP(3);
                     break;
                 }
                 if (tc_max < h) {                             /* :97-100 */
@@ -408,6 +416,7 @@ void orc_cast_ray(const orc_lnode *raw_data, uint32_t depth,
                 if (thy > t_min) { child_offset ^= 2u; posy += scale_f; }
                 if (thz > t_min) { child_offset ^= 4u; posz += scale_f; }
                 t_max = tv_max;                               /* :110 */
+                ORC_OP(0);
                 continue;
             }
         }
@@ -419,6 +428,7 @@ void orc_cast_ray(const orc_lnode *raw_data, uint32_t depth,
         t_min = tc_max;                                       /* :120-122 */
         child_offset ^= (uint8_t)step_mask;
         normal = (uint8_t)step_mask;
+        ORC_OP((child_offset & step_mask) ? 2 : 1);
         if (child_offset & step_mask) {                       /* :124 pop */
             uint32_t differing_bits = 0u;
             const int32_t ipx = (int32_t)f2u(posx), ipy = (int32_t)f2u(posy), ipz = (int32_t)f2u(posz);
@@ -676,12 +686,16 @@ typedef struct {
     uint64_t rays, sum_complexity;
     uint16_t *trace;           /* analysis hook (orc_render_frame_trace): complexity of this pixel's rays, in cast order */
     uint32_t trace_n;
+    uint8_t *ops;              /* analysis hook: this pixel's per-iteration op codes, ORC_TRACE_RAYS x ops_len bytes */
+    uint32_t ops_len;
 } shade_ctx;
 
 static void ctx_cast(shade_ctx *c, v3 o, v3 d, float coef, float bias, orc_hit *out)
 {
     const float of[3] = { o.x, o.y, o.z }, df[3] = { d.x, d.y, d.z };
+    if (c->ops && c->trace_n < ORC_TRACE_RAYS) { orc_optrace = c->ops + (size_t)c->trace_n * c->ops_len; orc_optrace_cap = c->ops_len; }
     orc_cast_ray(c->nodes, c->depth, of, df, coef, bias, out);
+    orc_optrace = 0;
     c->rays += 1;
     c->sum_complexity += out->complexity;
     if (c->trace && c->trace_n < ORC_TRACE_RAYS)
@@ -731,6 +745,10 @@ static void texture_color(const shade_ctx *c, const orc_hit *pt, uint8_t out[3])
     if (idx > 255u) idx = 255u;
     out[0] = img[idx * 3 + 0]; out[1] = img[idx * 3 + 1]; out[2] = img[idx * 3 + 2];
 }
+
+/* analysis hook: per-pixel op traces of the frame being rendered (set by orc_render_frame_optrace) */
+static uint8_t *orc_frame_ops;
+static uint32_t orc_frame_ops_len;
 
 /* raycaster.hpp:169-207; `level` > 0 only for the gi_bounces >= 2 extension. */
 static float global_illumination(shade_ctx *c, const orc_hit *point, rng_t *rng, float inv_size,
@@ -829,6 +847,8 @@ static void render_pixel(shade_ctx *c, const orc_camera *cam, const orc_frame_pa
     const uint32_t W = p->width, H = p->height;
     c->trace = trace ? trace + ((uint64_t)y * W + x) * ORC_TRACE_RAYS : 0;
     c->trace_n = 0;
+    c->ops = (trace && orc_frame_ops) ? orc_frame_ops + ((uint64_t)y * W + x) * ORC_TRACE_RAYS * orc_frame_ops_len : 0;
+    c->ops_len = orc_frame_ops_len;
     const float inv_size = 1.0f / (float)(1u << c->depth);     /* main.cpp:82 */
     rng_t rng = { p->rng_mode, p->seed, p->frame_index, y * W + x, 0u };
     /* main.cpp:133,145-146 */
@@ -889,7 +909,7 @@ void orc_render_frame_trace(const orc_lnode *nodes, uint32_t depth,
         /* serial: the reference's own pixel order within its 4x4 tiles is
          * thread-racy; x-outer/y-inner (main.cpp:142-143) over the whole frame here */
         shade_ctx c = { nodes, depth, tex_top, tex_side,
-                        { p->light_position[0], p->light_position[1], p->light_position[2] }, 0, 0, 0, 0 };
+                        { p->light_position[0], p->light_position[1], p->light_position[2] }, 0, 0, 0, 0, 0, 0 };
         for (uint32_t x = 0; x < W; x++)
             for (uint32_t y = 0; y < H; y++)
                 if (pixel_selected(p, x, y))
@@ -899,7 +919,7 @@ void orc_render_frame_trace(const orc_lnode *nodes, uint32_t depth,
 #pragma omp parallel for schedule(dynamic, 4) num_threads(threads) reduction(+ : rays, sumc)
         for (int32_t y = 0; y < (int32_t)H; y++) {
             shade_ctx c = { nodes, depth, tex_top, tex_side,
-                            { p->light_position[0], p->light_position[1], p->light_position[2] }, 0, 0, 0, 0 };
+                            { p->light_position[0], p->light_position[1], p->light_position[2] }, 0, 0, 0, 0, 0, 0 };
             for (uint32_t x = 0; x < W; x++)
                 if (pixel_selected(p, x, (uint32_t)y))
                     render_pixel(&c, cam, p, x, (uint32_t)y, image, accum, prim, trace);
@@ -909,6 +929,21 @@ void orc_render_frame_trace(const orc_lnode *nodes, uint32_t depth,
     if (prim)
         for (uint64_t i = 0; i < (uint64_t)W * H; i++) hits += prim[i].hit ? 1 : 0;
     if (stats) { stats->rays = rays; stats->sum_complexity = sumc; stats->primary_hits = hits; }
+}
+
+/* orc_render_frame_trace plus, per pixel and ray, one op code per loop iteration (see orc_cast_ray) into
+ * ops[(pixel * ORC_TRACE_RAYS + ray) * ops_len + iteration].  Not re-entrant (analysis only). */
+void orc_render_frame_optrace(const orc_lnode *nodes, uint32_t depth,
+                              const uint8_t tex_top[768], const uint8_t tex_side[768],
+                              const orc_camera *cam, const orc_frame_params *p,
+                              int threads, uint16_t *trace, uint8_t *ops, uint32_t ops_len)
+{
+    uint8_t *image = (uint8_t *)calloc((size_t)p->width * p->height, 4);
+    uint32_t *accum = (uint32_t *)calloc((size_t)p->width * p->height, 16);
+    orc_frame_ops = ops; orc_frame_ops_len = ops_len;
+    orc_render_frame_trace(nodes, depth, tex_top, tex_side, cam, p, image, accum, 0, 0, threads, trace);
+    orc_frame_ops = 0; orc_frame_ops_len = 0;
+    free(image); free(accum);
 }
 
 /* The same frame with the REFERENCE's own decomposition (main.cpp:90-92,139-152): 16 threads, thread t owns the
@@ -928,7 +963,7 @@ void orc_render_frame_areas16(const orc_lnode *nodes, uint32_t depth,
 #pragma omp for schedule(static, 1)
         for (int t = 0; t < 16; t++) {
             shade_ctx c = { nodes, depth, tex_top, tex_side,
-                            { p->light_position[0], p->light_position[1], p->light_position[2] }, 0, 0, 0, 0 };
+                            { p->light_position[0], p->light_position[1], p->light_position[2] }, 0, 0, 0, 0, 0, 0 };
             const uint32_t x0 = ((uint32_t)t % 4u) * aw, y0 = ((uint32_t)t / 4u) * ah;
             for (uint32_t x = x0; x < x0 + aw; x++)
                 for (uint32_t y = y0; y < y0 + ah; y++)

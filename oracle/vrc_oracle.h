@@ -160,6 +160,12 @@ void orc_render_frame_trace(const orc_lnode *nodes, uint32_t depth,
                             const orc_camera *cam, const orc_frame_params *p,
                             uint8_t *image, uint32_t *accum, orc_hit *prim,
                             orc_frame_stats *stats, int threads, uint16_t *trace);
+/* ... and one op code per loop iteration of each of those rays (0 descend, 1 advance, 2 advance + pop, 3 the iteration
+ * ending in a hit) into ops[(pixel * ORC_TRACE_RAYS + ray) * ops_len + iteration] (tools/path_schedule.py). */
+void orc_render_frame_optrace(const orc_lnode *nodes, uint32_t depth,
+                              const uint8_t tex_top[768], const uint8_t tex_side[768],
+                              const orc_camera *cam, const orc_frame_params *p,
+                              int threads, uint16_t *trace, uint8_t *ops, uint32_t ops_len);
 /* raycaster.hpp:94-103 / :105-116 */
 void orc_samples_to_image(const uint32_t *accum, uint32_t width, uint32_t height, uint8_t *image);
 

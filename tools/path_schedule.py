@@ -1,0 +1,118 @@
+#!/usr/bin/env python3
+"""Offline study (CPU, oracle only): instruction issue of the walk loop under different ways of scheduling its three
+divergent paths inside a wave, from the oracle's per-iteration op traces (orc_render_frame_optrace) of a strided band of
+the C3 frame.  A wave issues a block at full cost whenever ANY of its lanes needs it; per round (vrc_walk.h):
+header 13 VALU (15 with the LOD test), descend 25, advance 15, pop 22.  ANALYSIS INFRASTRUCTURE: uses oracle/ only.
+
+    python tools/path_schedule.py [--band 16]
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+H_, D_, A_, P_ = 13.0, 25.0, 15.0, 22.0
+
+
+def simulate(ops, length, policy, lod):
+    """ops: (64, L) uint8 op codes, length: (64,) iterations per lane (0 = no ray).  Returns issued VALU instructions."""
+    n = len(length)
+    pos = np.zeros(n, np.int64)           # next iteration of each lane
+    waiting_pop = np.zeros(n, bool)       # header + advance done, pop outstanding
+    cost = 0.0
+    h_cost = H_ + (2.0 if lod else 0.0)
+    k = policy.get("pop_every", 1)
+    thr = policy.get("pop_threshold", 1)
+    rnd = 0
+    while True:
+        active = (pos < length) & ~waiting_pop
+        if not active.any() and not waiting_pop.any():
+            break
+        rnd += 1
+        if active.any():
+            cur = ops[np.arange(n), np.minimum(pos, ops.shape[1] - 1)]
+            cost += h_cost
+            d = active & (cur == 0)
+            a = active & ((cur == 1) | (cur == 2))
+            if d.any():
+                cost += D_
+            if a.any():
+                cost += A_
+            need_pop = active & (cur == 2)
+            waiting_pop |= need_pop
+            pos[active & ~need_pop] += 1        # descend / plain advance / exit complete this round
+        # pop block: by policy
+        nwait = int(waiting_pop.sum())
+        run_pop = False
+        if nwait:
+            others = ((pos < length) & ~waiting_pop).any()
+            if k > 1:
+                run_pop = (rnd % k == 0) or not others
+            else:
+                run_pop = nwait >= thr or not others
+        if run_pop:
+            cost += P_
+            pos[waiting_pop] += 1
+            waiting_pop[:] = False
+    return cost, rnd
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--band", type=int, default=32, help="render 1 / band of the 8-row blocks")
+    ap.add_argument("--tiles", type=int, default=600)
+    ap.add_argument("--threads", type=int, default=os.cpu_count() or 1)
+    a = ap.parse_args()
+    import cpuvoxelraycaster_amd as vrc
+    import oracle_lib as O
+    depth, W, Hh = 9, 1920, 1080
+    nodes = vrc.build_terrain_lsvo(O.load_terrain_heights(), depth)
+    tex = O.load_textures()
+    cam = vrc.reference_camera(depth, pitch=-0.5, make_rotation=lambda x, y: O.make_rotation(x, y))
+    ocam = O.make_camera(tuple(cam.position), tuple(cam.rot), cam.fov, cam.aperture, cam.focal_length)
+    L = O.lib()
+    LEN = 192
+    trace = np.zeros((Hh, W, 8), np.uint16)
+    ops = np.zeros((Hh, W, 8, LEN), np.uint8)
+    p = O.make_params(W, Hh, vrc.reference_light(depth), use_gi=1, use_samples=1, shadow_samples=1, row_block=8,
+                      shard_index=a.band // 2, shard_count=a.band)
+    L.orc_render_frame_optrace.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(O.Camera),
+                                           C.POINTER(O.FrameParams), C.c_int, C.c_void_p, C.c_void_p, C.c_uint32]
+    L.orc_render_frame_optrace(O._ptr(nodes), depth, O._ptr(tex[0]), O._ptr(tex[1]), C.byref(ocam), C.byref(p), a.threads,
+                               O._ptr(trace), O._ptr(ops), LEN)
+    rows = [y for y in range(Hh) if (y // 8) % a.band == a.band // 2 and y // 8 * 8 + 8 <= Hh]
+    blocks = sorted({y // 8 for y in rows})
+    tiles = [(b, tx) for b in blocks for tx in range(W // 8)]
+    rng = np.random.default_rng(0)
+    rng.shuffle(tiles)
+    tiles = tiles[:a.tiles]
+    policies = {"now (pop whenever a lane needs it)": {},
+                "pop every 2nd round": {"pop_every": 2}, "pop every 3rd round": {"pop_every": 3},
+                "pop when >= 8 lanes wait": {"pop_threshold": 8}, "pop when >= 16 lanes wait": {"pop_threshold": 16},
+                "pop when >= 24 lanes wait": {"pop_threshold": 24}, "pop when >= 32 lanes wait": {"pop_threshold": 32}}
+    names = ["primary", "shadow", "GI", "GI shadow"]
+    tot = {k: np.zeros(4) for k in policies}
+    rounds = {k: np.zeros(4) for k in policies}
+    for (b, tx) in tiles:
+        for st in range(4):
+            o = ops[b * 8:b * 8 + 8, tx * 8:tx * 8 + 8, st].reshape(64, LEN)
+            ln = trace[b * 8:b * 8 + 8, tx * 8:tx * 8 + 8, st].reshape(64).astype(np.int64)
+            for k, pol in policies.items():
+                c, r = simulate(o, ln, pol, lod=st >= 2)
+                tot[k][st] += c
+                rounds[k][st] += r
+    base = tot["now (pop whenever a lane needs it)"]
+    print(f"{len(tiles)} tiles; issued VALU instructions per tile-sample and stage (rounds in brackets)")
+    for k in policies:
+        line = "  ".join(f"{names[i]} {tot[k][i] / len(tiles):7.0f} [{rounds[k][i] / len(tiles):5.1f}]" for i in range(4))
+        print(f"{k:36s} {line}   total {tot[k].sum() / len(tiles):7.0f} ({(tot[k].sum() / base.sum() - 1) * 100:+5.1f} %)")
+
+
+if __name__ == "__main__":
+    main()
