@@ -80,3 +80,40 @@ def test_present_on_the_renderers_framebuffer(built, heights, textures):
         pr.present(rc, median=4)
     with pytest.raises(vrc.VrcError):
         vrc.Presenter((W + 1, H), (OW, OH)).present(rc)
+
+
+def test_sharded_frame_through_the_present_chain(built, heights, textures):
+    """The multi-GPU frame path end to end on one GPU: three row-block shards rendered and resolved into their
+    all-gather slots, vrc_unpack_shards composes the frame, vrc_present_image runs the chain on it (5x5 network) --
+    equal to the oracle's chain on the oracle's unsharded frame."""
+    import torch
+    import cpuvoxelraycaster_amd as vrc
+    depth, W, H, OW, OH, RB, N = 7, 200, 100, 267, 133, 8, 3
+    nodes = vrc.build_terrain_lsvo(heights, depth)
+    svo = vrc.LSVO(nodes, depth, textures=textures)
+    top, side = textures
+    light = vrc.reference_light(depth)
+    cam = vrc.reference_camera(depth, pitch=-0.5)
+    L = vrc.capi.load()
+    nbytes = L.vrc_shard_bytes(W, H, RB, N)
+    gathered = torch.zeros(N * nbytes, dtype=torch.uint8, device="cuda")
+    for k in range(N):
+        rc = vrc.RayCaster(svo, (W, H))
+        rc.setLightPosition(light)
+        rc.use_gi = rc.use_samples = True
+        rc.shadow_samples = 1
+        rc.renderFrame(cam, spp=2, row_block=RB, shard_index=k, shard_count=N)
+        rc.resolveShard(RB, k, N, gathered.data_ptr() + k * nbytes, reset=True)
+    frame = torch.zeros(H * W * 4, dtype=torch.uint8, device="cuda")
+    vrc.capi.check(L.vrc_unpack_shards(vrc.capi.ptr(gathered.data_ptr()), W, H, RB, N, vrc.capi.ptr(frame.data_ptr()), None))
+    pr = vrc.Presenter((W, H), (OW, OH))
+    pr.presentImage(frame.data_ptr(), 0.0, median=5)
+    win, den = pr.read()
+    ocam = O.make_camera(tuple(cam.position), tuple(cam.rot), cam.fov, cam.aperture, cam.focal_length)
+    acc = None
+    for s in range(2):
+        p = O.make_params(W, H, light, use_gi=1, use_samples=1, shadow_samples=1, frame_index=s)
+        _, acc, _, _ = O.render_frame(nodes, depth, top, side, ocam, p, accum=acc, threads=8)
+    oden = np.zeros((H, W, 4), np.uint8)
+    owin = orc_present(O.samples_to_image(acc), oden, 0.0, 5, (OW, OH))
+    assert np.array_equal(den, oden) and np.array_equal(win, owin)
