@@ -96,6 +96,7 @@ SYMBOLS = {
     "vrc_presenter_window_ptr": (_vp, [_vp]),
     "vrc_presenter_denoised_ptr": (_vp, [_vp]),
     "vrc_presenter_read": (_int, [_vp, _vp, _vp, _vp]),
+    "vrc_selftest_exact_arith": (_int, [_int, _vp]),
     "vrc_set_sample_chunk": (_int, [_u32]),
     "vrc_renderer_set_tuning": (_int, [_vp, _u32, _u32, _u32]),
     "vrc_renderer_set_kernel": (_int, [_vp, _u32]),

@@ -660,6 +660,24 @@ extern "C" int vrc_unpack_shards(const void* gathered_dev, uint32_t width, uint3
     return VRC_OK;
 }
 
+// The kernels replace some IEEE divisions / square roots by short sequences that are proven equal on the ranges they
+// are used on; this runs that proof on the device: every float bit pattern of those ranges (~4.3 x 10^9 evaluations, a
+// fraction of a second).  mismatches[0..3]: reciprocal, square root, 1 / sqrt composition, get_rand -- all must be 0.
+extern "C" int vrc_selftest_exact_arith(int device, uint64_t mismatches[4])
+{
+    if (!mismatches) return fail(VRC_ERR_INVALID, "vrc_selftest_exact_arith: null argument");
+    int rc = require_device(device, nullptr);
+    if (rc) return rc;
+    unsigned long long* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, 32));
+    hipError_t e = hipMemset(d, 0, 32);
+    if (e == hipSuccess) e = vrc::launch_selftest_exact_arith(d, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(mismatches, d, 32, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(VRC_ERR_HIP, "vrc_selftest_exact_arith: %s", hipGetErrorString(e));
+    return VRC_OK;
+}
+
 // ---------------------------------------------------------------------------
 // host helper: generateRotationMatrix (utils.cpp:94-100) = mat3(ry * rx) with
 // rx = rotate(I, -angle.x, Y), ry = rotate(I, -angle.y, X); glm::rotate is the

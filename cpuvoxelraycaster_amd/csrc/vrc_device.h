@@ -48,9 +48,27 @@ __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, fl
 {
     return (ax * bx + ay * by) + az * bz;
 }
+__device__ __forceinline__ float exact_rcp(float x);
+// sqrt(x), correctly rounded, for 2^-100 <= x < 2^126: y = v_rsq_f32(x), g = x * y ~ sqrt, h = y / 2; the residual
+// d = x - g * g is exact in one FMA and g + d * h rounds to the nearest float of the true root
+// (tools/micro/sqrt_exact.hip: equal to the IEEE sqrtf for every bit pattern with exponent field 25..254).
+__device__ __forceinline__ float exact_sqrt(float x)
+{
+    float y;
+    asm("v_rsq_f32_e32 %0, %1" : "=v"(y) : "v"(x));
+    const float g = x * y, h = 0.5f * y;
+    const float d = __builtin_fmaf(-g, g, x);
+    return __builtin_fmaf(d, h, g);
+}
+// glm::normalize: v * (1 / sqrt(dot(v, v))) -- two correctly rounded operations, then three products.  In the range
+// where the short sequences are proven exact they replace the IEEE expansions (~22 instructions -> 8); a zero, tiny,
+// huge, infinite or NaN squared length takes the IEEE path (same results by definition).
 __device__ __forceinline__ void normalize3(float& x, float& y, float& z)
 {
-    const float inv = 1.0f / sqrtf(dot3(x, y, z, x, y, z));
+    const float s = dot3(x, y, z, x, y, z);
+    float inv;
+    if (f2u(s) - 0x0D800000u < 0x7E800000u - 0x0D800000u) inv = exact_rcp(exact_sqrt(s));   // 2^-100 <= s < 2^126
+    else inv = 1.0f / sqrtf(s);
     x = x * inv; y = y * inv; z = z * inv;
 }
 
@@ -84,7 +102,12 @@ __device__ __forceinline__ uint32_t counter_rand(uint32_t seed, uint32_t frame, 
 // getRand (utils.cpp:77-81): 100 levels
 __device__ __forceinline__ float get_rand(uint32_t k, float mn, float mx)
 {
-    const float rand_val = (float)(k % 100u) / 100.0f;
+    // float(m) / 100.0f for m = 0..99, correctly rounded: q0 = m * RN(1/100), exact residual, one correction -- equal to
+    // the IEEE quotient for all 100 values (tools/micro/sqrt_exact.hip; vrc_selftest_exact_arith), 3 instructions for ~10
+    const float m = (float)(k % 100u);
+    const float y = 1.0f / 100.0f;
+    const float q0 = m * y;
+    const float rand_val = __builtin_fmaf(__builtin_fmaf(-100.0f, q0, m), y, q0);
     return mn + (mx - mn) * rand_val;
 }
 

@@ -79,6 +79,7 @@ hipError_t launch_sanitize_nodes(void* nodes, uint64_t n, hipStream_t st);   // 
 // deeper than `depth`), bit 2 = a node reachable at two different levels (cycle / mis-shared subtree).
 // level_dev: n bytes of scratch.
 hipError_t launch_validate_nodes(const void* nodes, uint64_t n, uint32_t depth, uint8_t* level_dev, uint32_t* flags_dev, hipStream_t st);
+hipError_t launch_selftest_exact_arith(unsigned long long* out_dev, hipStream_t st);
 void renderer_info(const vrc_renderer* r, int* device, uint32_t* width, uint32_t* height);
 void scene_free(vrc_scene* s);   // releases the device / pinned resources and deletes s
 hipError_t launch_pack_shard(const void* image, uint32_t W, uint32_t H, uint32_t row_block, uint32_t shard,

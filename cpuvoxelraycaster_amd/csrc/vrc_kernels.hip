@@ -1304,6 +1304,38 @@ extern "C" __global__ void k_sanitize_nodes(uint2* __restrict__ nodes, uint64_t 
     if (y != x) nodes[i].x = y;
 }
 
+// vrc_selftest_exact_arith: the short division / square-root sequences of vrc_device.h against the IEEE operations they
+// replace, over EVERY float bit pattern of the domains they are used on (out[0]: 1 / x for exponent fields 1..252, both
+// signs; out[1]: sqrt(x) for positive x with exponent fields 27..252; out[2]: normalize3's 1 / sqrt(s) composition on the
+// same range; out[3]: get_rand for all 100 quantisation levels and both ranges the renderer uses).  Counts mismatches.
+extern "C" __global__ void k_selftest_exact_arith(unsigned long long* __restrict__ out)
+{
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;   // 2^24 threads x 256 bit patterns
+    uint32_t bad_rcp = 0u, bad_sqrt = 0u, bad_norm = 0u, bad_rand = 0u;
+    for (uint32_t k = 0; k < 256u; ++k) {
+        const uint32_t bits = (uint32_t)(tid * 256u + k);
+        const uint32_t e = (bits >> 23) & 0xffu;
+        const float x = u2f(bits);
+        if (e >= 1u && e <= 252u && f2u(exact_rcp(x)) != f2u(1.0f / x)) ++bad_rcp;
+        if (!(bits >> 31) && e >= 27u && e <= 252u) {
+            const float s = sqrtf(x);
+            if (f2u(exact_sqrt(x)) != f2u(s)) ++bad_sqrt;
+            // normalize3 on (x', 0, 0) with x' * x' == x is not constructible for every x: check its inner composition
+            if (f2u(exact_rcp(exact_sqrt(x))) != f2u(1.0f / s)) ++bad_norm;
+        }
+    }
+    if (tid < 100u) {
+        const uint32_t kk = (uint32_t)tid + 100u * 1234567u;                 // k % 100 == tid
+        const float rv = (float)(kk % 100u) / 100.0f;
+        if (f2u(get_rand(kk, -1000.0f, 1000.0f)) != f2u(-1000.0f + (1000.0f - -1000.0f) * rv)) ++bad_rand;
+        if (f2u(get_rand(kk, -0.5f, 0.5f)) != f2u(-0.5f + (0.5f - -0.5f) * rv)) ++bad_rand;
+    }
+    if (bad_rcp) atomicAdd(out + 0, (unsigned long long)bad_rcp);
+    if (bad_sqrt) atomicAdd(out + 1, (unsigned long long)bad_sqrt);
+    if (bad_norm) atomicAdd(out + 2, (unsigned long long)bad_norm);
+    if (bad_rand) atomicAdd(out + 3, (unsigned long long)bad_rand);
+}
+
 // vrc_scene_create: structural validation of a caller-supplied array, so that a truncated or malformed one is an error
 // code and not an out-of-bounds gather in the walk.  Pass L visits the nodes first reached at level L (root = 0) and
 // hands level L + 1 to the child blocks of their non-leaf children.
@@ -1471,6 +1503,12 @@ hipError_t launch_validate_nodes(const void* nodes, uint64_t n, uint32_t depth, 
     for (uint32_t L = 0; L < depth; ++L)
         hipLaunchKernelGGL(k_validate_level, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, (const uint2*)nodes, n, depth, L,
                            level_dev, flags_dev);
+    return hipGetLastError();
+}
+
+hipError_t launch_selftest_exact_arith(unsigned long long* out_dev, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_selftest_exact_arith, dim3(1u << 16), dim3(256), 0, st, out_dev);
     return hipGetLastError();
 }
 

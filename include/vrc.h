@@ -258,6 +258,13 @@ void *vrc_presenter_denoised_ptr(vrc_presenter *p);               /* RGBA8 width
 /* Copies the window image and / or denoised_tex to host memory (either may be NULL).  Synchronous. */
 int vrc_presenter_read(vrc_presenter *p, uint8_t *window_rgba_host, uint8_t *denoised_rgba_host, void *stream);
 
+/* Self-test of the arithmetic shortcuts: the kernels compute -1 / |d| (lsvo.hpp:47), glm::normalize's 1 / sqrt and
+ * getRand's x / 100 (utils.cpp:77-81) by v_rcp_f32 / v_rsq_f32 + one FMA correction step where that is proven equal to
+ * the correctly rounded IEEE result, and by the IEEE expansion elsewhere.  This runs the proof on `device`: every float
+ * bit pattern of the ranges concerned against the IEEE operations.  mismatches[0..3] = reciprocal, square root,
+ * 1 / sqrt, get_rand; all zero on a conforming device. */
+int vrc_selftest_exact_arith(int device, uint64_t mismatches[4]);
+
 /* Host helper: generateRotationMatrix (utils.cpp:94-100) for Camera::setViewAngle. */
 void vrc_make_rotation(float angle_x, float angle_y, float rot[9]);
 

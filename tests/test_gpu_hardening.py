@@ -167,3 +167,13 @@ def test_single_ray_slot(built, heights):
     assert not errors
     assert out.tobytes() == ref.tobytes()
     assert rc.stats().pixels == 640 * 360 * 4
+
+
+def test_arithmetic_shortcuts_are_exact(built):
+    """-1 / |d|, normalize's 1 / sqrt and getRand's / 100 use v_rcp_f32 / v_rsq_f32 + one FMA correction inside ranges where
+    that equals the correctly rounded IEEE result: checked here for EVERY float bit pattern of those ranges (2^32
+    reciprocals, 2^31 roots) on the device that runs the tests."""
+    from cpuvoxelraycaster_amd import capi
+    out = np.zeros(4, np.uint64)
+    capi.check(capi.load().vrc_selftest_exact_arith(0, capi.ptr(out)))
+    assert out.tolist() == [0, 0, 0, 0]
