@@ -310,7 +310,7 @@ void orc_terrain_heights(int32_t size, int32_t seed, int32_t *height)
 #define ORC_MAX_DEPTH 16
 #define ORC_MAX_ITERATIONS 65536u
 
-/* Analysis hook (tools/path_schedule.py): when set, the walk appends one byte per loop iteration -- 0 descend,
+/* Analysis hook (tests/tools/path_schedule.py): when set, the walk appends one byte per loop iteration -- 0 descend,
  * 1 advance, 2 advance + pop, 3 the iteration that ends in a leaf / LOD hit -- up to orc_optrace_cap bytes. */
 static __thread uint8_t *orc_optrace;
 static __thread uint32_t orc_optrace_cap;

@@ -161,7 +161,7 @@ void orc_render_frame_trace(const orc_lnode *nodes, uint32_t depth,
                             uint8_t *image, uint32_t *accum, orc_hit *prim,
                             orc_frame_stats *stats, int threads, uint16_t *trace);
 /* ... and one op code per loop iteration of each of those rays (0 descend, 1 advance, 2 advance + pop, 3 the iteration
- * ending in a hit) into ops[(pixel * ORC_TRACE_RAYS + ray) * ops_len + iteration] (tools/path_schedule.py). */
+ * ending in a hit) into ops[(pixel * ORC_TRACE_RAYS + ray) * ops_len + iteration] (tests/tools/path_schedule.py). */
 void orc_render_frame_optrace(const orc_lnode *nodes, uint32_t depth,
                               const uint8_t tex_top[768], const uint8_t tex_side[768],
                               const orc_camera *cam, const orc_frame_params *p,

@@ -4,7 +4,7 @@ divergent paths inside a wave, from the oracle's per-iteration op traces (orc_re
 the C3 frame.  A wave issues a block at full cost whenever ANY of its lanes needs it; per round (vrc_walk.h):
 header 13 VALU (15 with the LOD test), descend 25, advance 15, pop 22.  ANALYSIS INFRASTRUCTURE: uses oracle/ only.
 
-    python tools/path_schedule.py [--band 16]
+    python tests/tools/path_schedule.py [--band 16]
 """
 import argparse
 import ctypes as C
@@ -13,7 +13,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 

@@ -3,7 +3,7 @@
 under different ways of grouping a work unit's rays, from the oracle's per-ray loop-iteration counts
 (orc_render_frame_trace).  TEST/ANALYSIS INFRASTRUCTURE: uses oracle/, never the product path.
 
-    python tools/stage_balance.py [--width 1920 --height 1080 --depth 9 --spp 4]
+    python tests/tools/stage_balance.py [--width 1920 --height 1080 --depth 9 --spp 4]
 """
 import argparse
 import ctypes as C
@@ -12,7 +12,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
