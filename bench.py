@@ -363,6 +363,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
+    host_enqueue_us = (time.perf_counter() - t0) / args.steps * 1e6   # host time to issue a frame (no waiting on the GPU unless a slot is busy)
     drain()                                                    # the last frames' gathers are inside the timed region
     if dist_on:
         dist.barrier()
@@ -540,7 +541,7 @@ def main():
                        "loop_iterations_per_frame": steps_sum // args.steps,
                        "camera_pitch": args.pitch, "lsvo_nodes": svo.n_nodes,
                        "lsvo_gpu_build_ms": round(svo.build_ms, 3), "lsvo_gpu_build_call_ms": round(build_call_ms, 3),
-                       "frames_in_flight": F, "sharding": f"{ROW_BLOCK}-row blocks round-robin over {world} GPU(s)"
+                       "frames_in_flight": F, "host_enqueue_us_per_step": round(host_enqueue_us, 1), "sharding": f"{ROW_BLOCK}-row blocks round-robin over {world} GPU(s)"
                        + (f", RCCL {'gather to rank 0' if args.gather == 'root' else 'all-gather'} of RGBA8 shards" if dist_on else ""),
                        "ranks_in_process_group": (dist.get_world_size() if dist_on else 1),
                        "gathered_frame_equals_unsharded": verified},

@@ -242,3 +242,20 @@ def test_stray_leaf_bits_are_ignored(built, heights):
     back = svo.downloadNodes()
     assert np.array_equal(back["leaf_mask"], nodes["leaf_mask"] & nodes["child_mask"])
     assert np.array_equal(back["child_mask"], nodes["child_mask"]) and np.array_equal(back["child_offset"], nodes["child_offset"])
+
+
+@pytest.mark.parametrize("exp2", [-120, -101, -99, -60, -24, 60, 100, 125, 126, 127])
+def test_direction_magnitudes_across_the_shortcut_guards(terrain, exp2):
+    """Directions scaled by 2^k (the operator takes non-unit directions): t_coef = -1 / |d| switches between the exact
+    v_rcp_f32 + Newton form and the IEEE division at |d| = 2^126, and for huge |d| the t values are denormal --
+    every field must still equal the oracle's, LOD arguments included."""
+    nodes, svo = terrain[9]
+    org, d = raygen.camera_rays(9, 192, 108, -0.5)
+    o2, d2 = raygen.mixed_rays(4096, 1000 + exp2)
+    org, d = np.concatenate([org, o2]), np.concatenate([d, d2])
+    with np.errstate(over="ignore"):
+        d = (d.astype(np.float64) * 2.0 ** exp2).astype(np.float32)   # the non-unit rays of the set overflow to inf at 2^126: misses on both sides
+    assert_hits_equal(svo.castRays(org, d), O.cast_rays(nodes, 9, org, d, threads=8))
+    coef = np.full(len(org), 0.5, np.float32)
+    bias = np.where(np.arange(len(org)) % 3 == 0, 1e-3, 0.0).astype(np.float32)
+    assert_hits_equal(svo.castRays(org, d, coef, bias), O.cast_rays(nodes, 9, org, d, coef, bias, threads=8))
