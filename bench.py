@@ -13,7 +13,8 @@ actually executed (counted by the kernel, equal to the oracle's count).
 Frames are independent, and a launch of the persistent frame kernel is mostly
 tail at its end: the last work units finish at latency speed while most of the
 chip idles (~4 % of a 1080p frame on one GPU, more on a multi-GPU shard).  So two
-renderers / streams alternate by default (`--inflight 2`): the end of one launch
+renderers / streams alternate by default (`--inflight 2`; 4 from four GPUs on,
+where a rank's launch is only two or three work units deep): the end of one launch
 overlaps the start of the next frame, just as the exchange of frame i overlaps
 the renders after it.  ms_per_step is then the steady-state frame PERIOD (all K
 frames are complete inside the timed region) and can be shorter than one
@@ -184,7 +185,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inflight", type=int, default=0,
                     help="frames in flight per GPU (renderers / streams used round-robin); 1 = one stream, each frame starts "
-                         "when the previous one has ended; 0 = default: 2")
+                         "when the previous one has ended; 0 = default: 2, and 4 from four GPUs on")
     ap.add_argument("--gather", default="all", choices=["all", "root"],
                     help="N > 1: how the RGBA8 row-block shards meet: 'all' = RCCL all-gather (every rank ends up with the "
                          "frame), 'root' = RCCL gather to rank 0, the presenting rank (north_star / SURVEY 8e: 1/N of the "
@@ -263,7 +264,7 @@ def main():
     # one launch (its last work units finish at latency speed with most of the chip idle) overlaps the start of the
     # next frame's launch, like the all-gather of frame i overlaps the render of frame i + 1.  Frames stay independent
     # and complete in order; F = 1 is the plain one-stream loop.
-    F = args.inflight if args.inflight > 0 else 2
+    F = args.inflight if args.inflight > 0 else (2 if world <= 2 else 4)
 
     def make_renderer():
         r = vrc.RayCaster(svo, (W, H))

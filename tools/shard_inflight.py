@@ -18,7 +18,7 @@ cam = vrc.reference_camera(depth, pitch=-0.5)
 L = vrc.capi.load()
 print("N  inflight  us/frame")
 for N in (1, 2, 4, 8):
-    for F in (1, 2):
+    for F in (1, 2, 3, 4):
         rcs = []
         for _ in range(F):
             rc = vrc.RayCaster(svo, (W, H))
