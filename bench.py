@@ -94,7 +94,8 @@ def cpu_baseline(cfg, nodes, textures, cam, light, budget_s=3.5):
     """The oracle (bit-identical CPU restatement, kind "port") timed on this box's host cores on a bounded sample of
     the same workload: whole frame-samples (every pixel once: 1/spp of a frame), three ways:
       4x4x16     the reference's own decomposition: 16 threads, thread t owns area (t % 4, t / 4), x-outer / y-inner
-                 (main.cpp:90-92,139-152), parity build (-O2 -ffp-contract=off)
+                 (main.cpp:90-92,139-152), parity build (-O2 -ffp-contract=off) -- on OpenMP threads and, where
+                 oracle/_ref/libref_swarm.so exists, on the reference's own swarm thread pool
       omp        OpenMP dynamic rows on 16 / 32 / 64 / all usable host cores, parity build -- the fastest is the headline
                  `value` (with its thread count as `cores`)
       native     the same source built -O3 -march=native with FMA contraction allowed: NON-parity (its results may
@@ -150,10 +151,40 @@ def cpu_baseline(cfg, nodes, textures, cam, light, budget_s=3.5):
         dt = time.perf_counter() - t0
         return rays, n, dt
 
+    # a process's first second or so of multi-threaded work runs several times slower than the steady state on these
+    # hosts (thread start-up, first touches, frequency): spend it before anything is timed
+    t_w = time.perf_counter()
+    while time.perf_counter() - t_w < 1.5:
+        run_once = O.make_params(W, H, light, use_gi=cfg["use_gi"], use_samples=1, shadow_samples=1, gi_bounces=cfg.get("gi_bounces", 1))
+        L.orc_render_frame(O._ptr(nodes), cfg["depth"], O._ptr(top), O._ptr(side), C.byref(ocam), C.byref(run_once), O._ptr(img),
+                           O._ptr(acc), None, C.byref(O.FrameStats()), min(16, usable))
     out = []
     r, n, dt = run("areas16", 16)
     out.append({"decomp": "4x4x16", "threads": 16, "flags": "-O2 -ffp-contract=off", "parity": True,
                 "value": round(r / dt / 1e6, 3), "frame_samples": n, "seconds": round(dt, 2)})
+    if O.RefSwarm.available():
+        # the same decomposition on the reference's OWN thread pool (lib/swarm/swarm.hpp compiled where it lies into
+        # oracle/_ref/libref_swarm.so; the .so travels to the GPU box): Swarm(16), execute(lambda), waitExecutionDone()
+        # exactly as main.cpp:90,139,154; the lambda's body is the oracle's per-area job
+        sw = O.RefSwarm(16)
+        rays_sw = 0
+        n_sw = -1
+        t0 = time.perf_counter()
+        while n_sw <= 0 or time.perf_counter() - t0 < budget_s:
+            if n_sw == 0:
+                rays_sw = 0
+                sw.retries = 0
+                t0 = time.perf_counter()
+            p = O.make_params(W, H, light, use_gi=cfg["use_gi"], use_samples=1, shadow_samples=1, frame_index=max(n_sw, 0),
+                              gi_bounces=cfg.get("gi_bounces", 1))
+            _, _, st = sw.render_frame(nodes, cfg["depth"], top, side, ocam, p, image=img, accum=acc)
+            rays_sw += st.rays
+            n_sw += 1
+        dt_sw = time.perf_counter() - t0
+        out.append({"decomp": "4x4x16 on the reference's own swarm pool (swrm::Swarm(16), lib/swarm/swarm.hpp)", "threads": 16,
+                    "flags": "-O2 -ffp-contract=off", "parity": True, "value": round(rays_sw / dt_sw / 1e6, 3),
+                    "frame_samples": n_sw, "seconds": round(dt_sw, 2), "dropped_executes_retried": sw.retries})
+        sw.close()
     # OpenMP over a few thread counts: on a shared host more threads are not always faster -- the fastest is the headline
     counts = sorted({c for c in (16, 32, 64, usable) if c <= usable} or {usable})
     best = None

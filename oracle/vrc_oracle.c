@@ -975,6 +975,27 @@ void orc_render_frame_areas16(const orc_lnode *nodes, uint32_t depth,
     if (stats) { stats->rays = rays; stats->sum_complexity = sumc; stats->primary_hits = 0; }
 }
 
+/* One worker's share of a frame under the reference's decomposition, as a job a thread pool can call: worker `id` renders
+ * area (id % 4, id / 4) of (W/4) x (H/4) pixels, x-outer / y-inner -- the body of the swarm lambda, main.cpp:139-152.
+ * `user` is an orc_area_frame; rays / complexity are summed per worker (no shared counters).  bench.py hands this
+ * function to the reference's own swarm pool (oracle/_ref/libref_swarm.so). */
+void orc_area_job(uint32_t id, uint32_t worker_count, void *user)
+{
+    (void)worker_count;
+    orc_area_frame *f = (orc_area_frame *)user;
+    const orc_frame_params *p = f->params;
+    const uint32_t aw = p->width / 4u, ah = p->height / 4u;
+    if (id >= 16u) return;
+    shade_ctx c = { f->nodes, f->depth, f->tex_top, f->tex_side,
+                    { p->light_position[0], p->light_position[1], p->light_position[2] }, 0, 0, 0, 0, 0, 0 };
+    const uint32_t x0 = (id % 4u) * aw, y0 = (id / 4u) * ah;
+    for (uint32_t x = x0; x < x0 + aw; x++)
+        for (uint32_t y = y0; y < y0 + ah; y++)
+            if (pixel_selected(p, x, y))
+                render_pixel(&c, f->cam, p, x, y, f->image, f->accum, 0, 0);
+    f->rays[id] = c.rays; f->sum_complexity[id] = c.sum_complexity;
+}
+
 /* raycaster.hpp:94-103: uint8(sum / count) in double == integer division for
  * integer sums (see vrc_oracle.h).  count == 0 (never-sampled pixel) is NaN ->
  * UB in the reference; black here. */

@@ -151,6 +151,19 @@ void orc_render_frame_areas16(const orc_lnode *nodes, uint32_t depth,
                               const uint8_t tex_top[768], const uint8_t tex_side[768],
                               const orc_camera *cam, const orc_frame_params *p,
                               uint8_t *image, uint32_t *accum, orc_frame_stats *stats);
+/* The swarm lambda's body as a thread-pool job (main.cpp:139-152): worker `id` of 16 renders its area.  `user` points
+ * to an orc_area_frame. */
+typedef struct orc_area_frame {
+    const orc_lnode *nodes;
+    uint32_t depth;
+    const uint8_t *tex_top, *tex_side;
+    const orc_camera *cam;
+    const orc_frame_params *params;
+    uint8_t *image;
+    uint32_t *accum;
+    uint64_t rays[16], sum_complexity[16];
+} orc_area_frame;
+void orc_area_job(uint32_t id, uint32_t worker_count, void *user);
 /* Analysis hook (tools/): the same frame, and per pixel the loop-iteration counts of its first ORC_TRACE_RAYS
  * castRay calls in cast order (primary, shadow..., GI, GI shadow, ...) into trace[pixel * ORC_TRACE_RAYS + k]
  * (untouched entries stay as the caller set them).  trace == NULL is orc_render_frame. */

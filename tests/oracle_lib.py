@@ -229,3 +229,61 @@ def samples_to_image(accum):
     img = np.zeros((H, W, 4), np.uint8)
     lib().orc_samples_to_image(_ptr(accum), W, H, _ptr(img))
     return img
+
+
+# ---- the reference's own thread pool (lib/swarm/swarm.hpp compiled where it lies into oracle/_ref/libref_swarm.so) ----
+
+REF_SWARM = os.path.join(ORACLE_DIR, "_ref", "libref_swarm.so")
+
+
+class AreaFrame(C.Structure):
+    _fields_ = [("nodes", C.c_void_p), ("depth", C.c_uint32), ("tex_top", C.c_void_p), ("tex_side", C.c_void_p),
+                ("cam", C.POINTER(Camera)), ("params", C.POINTER(FrameParams)), ("image", C.c_void_p), ("accum", C.c_void_p),
+                ("rays", C.c_uint64 * 16), ("sum_complexity", C.c_uint64 * 16)]
+
+
+class RefSwarm:
+    """swrm::Swarm(16) of the reference, driving the oracle's per-area frame job (orc_area_job = the body of the swarm
+    lambda, main.cpp:139-152).  Available where oracle/_ref/libref_swarm.so exists (built from /root/reference by
+    `make -C oracle ref`; the .so travels to the GPU box, the reference's sources do not)."""
+
+    def __init__(self, threads=16):
+        self.lib = C.CDLL(REF_SWARM)
+        self.lib.ref_swarm_create.restype = C.c_void_p
+        self.lib.ref_swarm_create.argtypes = [C.c_uint32]
+        self.lib.ref_swarm_destroy.argtypes = [C.c_void_p]
+        self.lib.ref_swarm_run.restype = C.c_uint32
+        self.lib.ref_swarm_run.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32]
+        self.threads = threads
+        self.h = self.lib.ref_swarm_create(threads)
+        self.job = C.cast(lib().orc_area_job, C.c_void_p)      # a plain C function pointer: no GIL on the workers
+        self.retries = 0
+
+    @staticmethod
+    def available():
+        return os.path.exists(REF_SWARM)
+
+    def render_frame(self, nodes, depth, tex_top, tex_side, cam, params, image=None, accum=None):
+        W, H = params.width, params.height
+        if image is None:
+            image = np.zeros((H, W, 4), np.uint8)
+            image[..., 3] = 255
+        if accum is None:
+            accum = np.zeros((H, W, 4), np.uint32)
+        f = AreaFrame()
+        f.nodes, f.depth = _ptr(nodes), depth
+        f.tex_top, f.tex_side = _ptr(tex_top), _ptr(tex_side)
+        f.cam, f.params = C.pointer(cam), C.pointer(params)
+        f.image, f.accum = _ptr(image), _ptr(accum)
+        tries = self.lib.ref_swarm_run(self.h, self.threads, self.job, C.byref(f), 1000)
+        if tries == 0:
+            raise RuntimeError("the swarm never ran the job")
+        self.retries += tries - 1
+        st = FrameStats()
+        st.rays, st.sum_complexity = sum(f.rays), sum(f.sum_complexity)
+        return image, accum, st
+
+    def close(self):
+        if self.h:
+            self.lib.ref_swarm_destroy(self.h)
+            self.h = None
