@@ -51,6 +51,38 @@ inline void check(int rc, const char* what)
     if (rc != VRC_OK) throw std::runtime_error(std::string(what) + ": " + vrc_last_error());
 }
 
+// The albedo tables as the reference gets them: sf::Image::loadFromFile("res/grass_top_16x16.bmp") and getPixel(x, y)
+// (raycaster.hpp:53-54,239) -- an uncompressed 24- or 32-bpp BMP decoded to RGB rows, top row first.  Returns
+// width * height * 3 bytes (768 for the reference's 16 x 16 files); throws on anything else.
+inline std::vector<uint8_t> loadBMP(const std::string& path, uint32_t* width = nullptr, uint32_t* height = nullptr)
+{
+    std::ifstream f(path, std::ios::binary);
+    std::vector<uint8_t> d((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    auto u32 = [&](size_t o) { return (uint32_t)d[o] | ((uint32_t)d[o + 1] << 8) | ((uint32_t)d[o + 2] << 16) | ((uint32_t)d[o + 3] << 24); };
+    auto u16 = [&](size_t o) { return (uint32_t)d[o] | ((uint32_t)d[o + 1] << 8); };
+    if (d.size() < 54 || d[0] != 'B' || d[1] != 'M') throw std::runtime_error("loadBMP: not a BMP file: " + path);
+    const uint32_t off = u32(10), bpp = u16(28), comp = u32(30);
+    const int32_t w = (int32_t)u32(18), hs = (int32_t)u32(22);
+    const uint32_t h = (uint32_t)(hs < 0 ? -hs : hs);
+    if (w <= 0 || h == 0 || (bpp != 24 && bpp != 32) || (comp != 0 && !(comp == 3 && bpp == 32)))
+        throw std::runtime_error("loadBMP: only uncompressed 24 / 32 bpp is supported: " + path);
+    const size_t stride = ((size_t)w * (bpp / 8) + 3) & ~(size_t)3;
+    if (d.size() < off + stride * h) throw std::runtime_error("loadBMP: truncated file: " + path);
+    std::vector<uint8_t> rgb((size_t)w * h * 3);
+    for (uint32_t row = 0; row < h; ++row) {
+        const uint32_t y = hs < 0 ? row : h - 1 - row;          // positive height: the file's first row is the bottom one
+        const uint8_t* line = d.data() + off + stride * row;
+        for (int32_t x = 0; x < w; ++x) {
+            const uint8_t* px = line + (size_t)x * (bpp / 8);    // B, G, R [, A]
+            uint8_t* o = rgb.data() + ((size_t)y * w + x) * 3;
+            o[0] = px[2]; o[1] = px[1]; o[2] = px[0];
+        }
+    }
+    if (width) *width = (uint32_t)w;
+    if (height) *height = h;
+    return rgb;
+}
+
 // LSVO<N> (lsvo.hpp:10): immutable, device resident; castRay is const and may be
 // called from any number of threads, like the reference's (main.cpp:139-152).
 class HipLSVO {
@@ -89,6 +121,18 @@ public:
         std::vector<HitPoint> out(n);
         for (uint64_t i = 0; i < n; ++i) out[i] = convert(raw[i]);
         return out;
+    }
+
+    // RayCaster's constructor loads the two 16 x 16 tables relative to the working directory (raycaster.hpp:53-54);
+    // here the caller names the files
+    void loadTextures(const std::string& top_bmp, const std::string& side_bmp)
+    {
+        uint32_t w = 0, h = 0;
+        const std::vector<uint8_t> top = loadBMP(top_bmp, &w, &h);
+        if (w != 16 || h != 16) throw std::runtime_error("loadTextures: " + top_bmp + " is not 16 x 16");
+        const std::vector<uint8_t> side = loadBMP(side_bmp, &w, &h);
+        if (w != 16 || h != 16) throw std::runtime_error("loadTextures: " + side_bmp + " is not 16 x 16");
+        check(vrc_scene_set_textures(scene_, top.data(), side.data()), "vrc_scene_set_textures");
     }
 
     vrc_scene* handle() const { return scene_; }

@@ -26,6 +26,36 @@ def load_textures():
     return top, side
 
 
+def load_bmp(path):
+    """An uncompressed 24- / 32-bpp BMP as sf::Image::loadFromFile + getPixel see it (raycaster.hpp:53-54,239): (h, w, 3)
+    uint8 RGB, top row first.  For pointing the renderer at the reference's res/grass_{top,side}_16x16.bmp directly."""
+    import struct
+    d = open(path, "rb").read()
+    if len(d) < 54 or d[:2] != b"BM":
+        raise ValueError(f"{path}: not a BMP file")
+    off = struct.unpack_from("<I", d, 10)[0]
+    w, hs, _planes, bpp, comp = struct.unpack_from("<iiHHI", d, 18)
+    h = abs(hs)
+    if w <= 0 or h == 0 or bpp not in (24, 32) or not (comp == 0 or (comp == 3 and bpp == 32)):
+        raise ValueError(f"{path}: only uncompressed 24 / 32 bpp is supported")
+    bpx = bpp // 8
+    stride = (w * bpx + 3) & ~3
+    out = np.zeros((h, w, 3), np.uint8)
+    for row in range(h):
+        y = row if hs < 0 else h - 1 - row
+        line = np.frombuffer(d, np.uint8, w * bpx, off + row * stride).reshape(w, bpx)
+        out[y] = line[:, 2::-1]                              # B, G, R [, A] -> R, G, B
+    return out
+
+
+def load_textures_bmp(top_path, side_path):
+    """(top, side) tables for LSVO(..., textures=...) from two 16 x 16 BMP files."""
+    top, side = load_bmp(top_path), load_bmp(side_path)
+    if top.shape != (16, 16, 3) or side.shape != (16, 16, 3):
+        raise ValueError("the albedo tables are 16 x 16")
+    return top.reshape(-1), side.reshape(-1)
+
+
 def reference_light(depth):
     """setLightPosition argument of main.cpp:124-126 for a 2^depth scene (SVO space)."""
     size = np.float32(1 << depth)

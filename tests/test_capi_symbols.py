@@ -98,3 +98,57 @@ def test_argument_validation_needs_no_gpu(built):
     assert L.vrc_resolve_shard(None, 8, 0, 1, None, 0, None) == -1
     assert L.vrc_unpack_shards(None, 16, 16, 8, 2, None, None) == -1
     assert L.vrc_shard_bytes(1920, 1080, 8, 8) == 17 * 8 * 1920 * 4
+
+
+def test_bmp_texture_readers(built, tmp_path):
+    """The data format in front of the path: the reference loads its two albedo tables from 16 x 16 BMP files
+    (raycaster.hpp:53-54).  The host adapter's loadBMP and the Python loader decode a 24-bpp bottom-up file (what the
+    reference ships), a 32-bpp one and a top-down one to the same top-down RGB table; where the reference is mounted,
+    its own files decode to the packaged tables."""
+    import struct
+    import subprocess
+    import cpuvoxelraycaster_amd as vrc
+    top, side = vrc.load_textures()
+    rgb = top.reshape(16, 16, 3)
+
+    def write_bmp(path, img, bpp, top_down):
+        h, w, _ = img.shape
+        bpx = bpp // 8
+        stride = (w * bpx + 3) & ~3
+        rows = []
+        for row in range(h):
+            y = row if top_down else h - 1 - row
+            px = img[y][:, ::-1]                                  # B, G, R
+            if bpp == 32:
+                px = np.concatenate([px, np.full((w, 1), 255, np.uint8)], 1)
+            line = px.tobytes()
+            rows.append(line + b"\0" * (stride - len(line)))
+        data = b"".join(rows)
+        hdr = b"BM" + struct.pack("<IHHI", 54 + len(data), 0, 0, 54)
+        hdr += struct.pack("<IiiHHIIiiII", 40, w, -h if top_down else h, 1, bpp, 0, len(data), 2835, 2835, 0, 0)
+        open(path, "wb").write(hdr + data)
+
+    variants = {"a24.bmp": (24, False), "a32.bmp": (32, False), "a24td.bmp": (24, True)}
+    for name, (bpp, td) in variants.items():
+        write_bmp(tmp_path / name, rgb, bpp, td)
+        assert np.array_equal(vrc.load_bmp(str(tmp_path / name)), rgb), name
+    odd = np.arange(7 * 5 * 3, dtype=np.uint8).reshape(5, 7, 3)      # row padding: 7 * 3 = 21 -> 24 bytes
+    write_bmp(tmp_path / "odd.bmp", odd, 24, False)
+    assert np.array_equal(vrc.load_bmp(str(tmp_path / "odd.bmp")), odd)
+    hdr = os.path.join(ROOT, "cpuvoxelraycaster_amd", "host", "hip_raycaster.hpp")
+    src = ('#include "%s"\n#include <cstdio>\nint main(int c, char** v){ uint32_t w, h; auto p = vrc_host::loadBMP(v[1], &w, &h);'
+           'std::fwrite(p.data(), 1, p.size(), stdout); std::fprintf(stderr, "%%u %%u", w, h); return 0; }\n') % hdr
+    exe = str(tmp_path / "bmp_test")
+    subprocess.run(["g++", "-std=c++14", "-x", "c++", "-", "-o", exe, "-L" + os.path.join(ROOT, "cpuvoxelraycaster_amd"),
+                    "-l:libvrc_hip.so", "-Wl,-rpath," + os.path.join(ROOT, "cpuvoxelraycaster_amd"), "-Wl,-rpath,/opt/rocm/lib"],
+                   input=src.encode(), check=True)
+    for name in list(variants) + ["odd.bmp"]:
+        out = subprocess.run([exe, str(tmp_path / name)], capture_output=True)
+        want = odd if name == "odd.bmp" else rgb
+        assert out.stderr.decode() == f"{want.shape[1]} {want.shape[0]}" and out.stdout == want.tobytes(), name
+    ref = "/root/reference/res"
+    if os.path.isdir(ref):
+        t, s = vrc.load_textures_bmp(os.path.join(ref, "grass_top_16x16.bmp"), os.path.join(ref, "grass_side_16x16.bmp"))
+        assert np.array_equal(t, top) and np.array_equal(s, side)
+        out = subprocess.run([exe, os.path.join(ref, "grass_side_16x16.bmp")], capture_output=True)
+        assert out.stdout == side.tobytes()
