@@ -109,6 +109,11 @@ def test_dof(scene, textures):
     run_pair(scene, textures, 9, 320, 180, -0.5, spp=2, use_gi=1, aperture=0.5, focal_length=60.0)
 
 
+def test_dof_two_bounce_extension(scene, textures):
+    """general camera + 2-bounce extension: the fourth specialisation of the stage-synchronous kernel (k_render_sync2)"""
+    run_pair(scene, textures, 7, 160, 90, -0.5, spp=3, use_gi=1, gi_bounces=2, aperture=0.7, focal_length=40.0)
+
+
 @pytest.mark.parametrize("aperture,focal_length", [(0.0, 1.0), (0.0, 37.5), (0.0, -1.0), (-0.0, 1.0), (0.0, 1e-35), (1e-30, 1.0)])
 def test_pinhole_shortcut_is_exact(scene, textures, aperture, focal_length):
     """aperture == +0 skips the two lens draws (rand_vec = 0 * getRand() is +-0): exact only while focal_point.x / .y

@@ -84,6 +84,17 @@ def main():
             cam = vrc.make_camera(pos, vrc.make_rotation(float(rng.uniform(-3, 3)), float(rng.uniform(-1.3, 0.3))),
                                   fov=float(rng.uniform(0.5, 1.5)), aperture=float(rng.choice([0.0, 0.3, 2.0])),
                                   focal_length=float(rng.uniform(1, 120)))
+            # the light of main.cpp:124 most of the time; sometimes anywhere -- inside the cube, far away, on a voxel
+            # boundary -- so that the shadow / GI-shadow directions and their normalisation leave the usual range
+            lk = int(rng.integers(0, 8))
+            if lk == 0:
+                light = rng.uniform(1.0, 2.0, 3).astype(np.float32)
+            elif lk == 1:
+                light = (rng.normal(size=3) * 10.0 ** rng.uniform(0, 30)).astype(np.float32)
+            elif lk == 2:
+                light = (np.round(rng.uniform(1.0, 2.0, 3) * S) / S).astype(np.float32)
+            if lk <= 2:
+                rc.setLightPosition(light)
             spp = int(rng.integers(1, 7))
             nfr = int(rng.integers(1, 3))
             checker = bool(rng.integers(0, 2))
