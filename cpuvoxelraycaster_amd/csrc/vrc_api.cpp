@@ -243,16 +243,46 @@ extern "C" uint32_t vrc_scene_depth(const vrc_scene* s) { return s ? s->depth : 
 
 namespace {
 
+// Device staging for the host-memory form of the batch operators: one grow-only block per device, kept between calls
+// (a hipMalloc / hipFree pair costs more than casting ten thousand rays, and hipFree synchronises the whole device),
+// at most VRC_STAGE_CACHE_MAX bytes; a call that finds the block in use by another thread, or needs more than that,
+// allocates privately.
+constexpr size_t VRC_STAGE_CACHE_MAX = 1ull << 30;
+struct StageCache {
+    std::mutex mu;
+    uint8_t* ptr = nullptr;
+    size_t cap = 0;
+};
+StageCache g_stage_cache[16];
+
 // Stage host ray buffers through device memory around `launch`.
 template <class Launch>
-int staged_cast(uint64_t n, const float* org, const float* dir, const float* coef, const float* bias, vrc_hit* out,
+int staged_cast(int device, uint64_t n, const float* org, const float* dir, const float* coef, const float* bias, vrc_hit* out,
                 hipStream_t st, Launch launch)
 {
-    // one allocation: hits (48 B, 16-byte aligned records first) | origins | directions | coef | bias
+    // one block: hits (48 B, 16-byte aligned records first) | origins | directions | coef | bias
+    const size_t need = n * (sizeof(vrc_hit) + 12 + 12 + 4 + 4);
+    StageCache* cache = (device >= 0 && device < 16 && need <= VRC_STAGE_CACHE_MAX) ? &g_stage_cache[device] : nullptr;
+    std::unique_lock<std::mutex> lk;
+    if (cache) {
+        lk = std::unique_lock<std::mutex>(cache->mu, std::try_to_lock);
+        if (!lk.owns_lock()) cache = nullptr;
+    }
     float *d_org = nullptr, *d_dir = nullptr, *d_coef = nullptr, *d_bias = nullptr;
     vrc_hit* d_out = nullptr;
     uint8_t* arena = nullptr;
-    hipError_t e = hipMalloc((void**)&arena, n * (sizeof(vrc_hit) + 12 + 12 + 4 + 4));
+    hipError_t e = hipSuccess;
+    if (cache) {
+        if (cache->cap < need) {
+            if (cache->ptr) (void)hipFree(cache->ptr);
+            cache->ptr = nullptr; cache->cap = 0;
+            e = hipMalloc((void**)&cache->ptr, need);
+            if (e == hipSuccess) cache->cap = need;
+        }
+        arena = cache->ptr;
+    } else {
+        e = hipMalloc((void**)&arena, need);
+    }
     if (e == hipSuccess) {
         d_out = (vrc_hit*)arena;
         d_org = (float*)(arena + n * sizeof(vrc_hit));
@@ -267,7 +297,7 @@ int staged_cast(uint64_t n, const float* org, const float* dir, const float* coe
     if (e == hipSuccess) e = launch(d_org, d_dir, d_coef, d_bias, d_out);
     if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, n * sizeof(vrc_hit), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    (void)hipFree(arena);
+    if (!cache && arena) (void)hipFree(arena);
     if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? VRC_ERR_OOM : VRC_ERR_HIP, "cast_rays: %s", hipGetErrorString(e));
     return VRC_OK;
 }
@@ -288,7 +318,7 @@ extern "C" int vrc_cast_rays(const vrc_scene* s, uint64_t n, const float* org_xy
         return VRC_OK;
     }
     if (mem != VRC_MEM_HOST) return fail(VRC_ERR_INVALID, "vrc_cast_rays: bad mem kind %d", mem);
-    return staged_cast(n, org_xyz, dir_xyz, coef, bias, out, st,
+    return staged_cast(s->device, n, org_xyz, dir_xyz, coef, bias, out, st,
                        [&](float* o, float* d, float* c, float* b, vrc_hit* h) {
                            return vrc::launch_cast_rays(s->d_nodes, (int)s->depth, n, o, d, c, b, h, st);
                        });
@@ -371,7 +401,7 @@ extern "C" int vrc_grid_cast_rays(const vrc_grid* g, uint64_t n, const float* or
         return VRC_OK;
     }
     if (mem != VRC_MEM_HOST) return fail(VRC_ERR_INVALID, "vrc_grid_cast_rays: bad mem kind %d", mem);
-    return staged_cast(n, org_xyz, dir_xyz, nullptr, nullptr, out, st,
+    return staged_cast(g->device, n, org_xyz, dir_xyz, nullptr, nullptr, out, st,
                        [&](float* o, float* d, float*, float*, vrc_hit* h) {
                            return vrc::launch_grid_cast((const uint8_t*)g->d_cells, g->X, g->Y, g->Z, n, o, d, h, st);
                        });

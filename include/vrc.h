@@ -127,7 +127,8 @@ int vrc_scene_build_fastnoise_terrain(int32_t seed, uint32_t depth, int device, 
 /* Batch form of HitPoint castRay(position, direction, ray_size_coef,
  * ray_size_bias).  org_xyz / dir_xyz: n x 3 floats; coef / bias: n floats or
  * NULL (= 0).  `mem` says where ALL ray and output buffers live
- * (VRC_MEM_HOST: staged through the library; VRC_MEM_DEVICE: used in place,
+ * (VRC_MEM_HOST: staged through the library, synchronous -- the staging block is kept
+ * per device between calls, grow-only up to 1 GiB; VRC_MEM_DEVICE: used in place,
  * asynchronous on `stream`). */
 int vrc_cast_rays(const vrc_scene *s, uint64_t n,
                   const float *org_xyz, const float *dir_xyz,

@@ -177,3 +177,34 @@ def test_arithmetic_shortcuts_are_exact(built):
     out = np.zeros(4, np.uint64)
     capi.check(capi.load().vrc_selftest_exact_arith(0, capi.ptr(out)))
     assert out.tolist() == [0, 0, 0, 0]
+
+
+def test_host_batch_calls_from_several_threads(built, heights):
+    """vrc_cast_rays with host buffers keeps one staging block per device between calls; threads that find it busy
+    allocate privately -- every call returns its own rays' HitPoints whatever the interleaving and the batch sizes."""
+    import cpuvoxelraycaster_amd as vrc
+    from raygen import mixed_rays
+    depth = 7
+    nodes = vrc.build_terrain_lsvo(heights, depth)
+    svo = vrc.LSVO(nodes, depth)
+    errors = []
+
+    def worker(k):
+        try:
+            for j in range(12):
+                n = [17, 4096, 1, 70000, 300][(j + k) % 5]
+                org, d = mixed_rays(max(n, 16), 100 * k + j)
+                org, d = org[:n], d[:n]
+                got = svo.castRays(org, d)
+                ref = O.cast_rays(nodes, depth, org, d)
+                if got.tobytes() != ref.tobytes():
+                    errors.append((k, j, n))
+        except Exception as e:      # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors
