@@ -112,8 +112,42 @@ def main():
                 acc += lanes.max(axis=1).mean()
             tot += acc / a.spp
         report(f"K={K} with work stealing inside the wave (greedy), GI + GI shadow", tot)
-    ideal = tr.sum(axis=(1, 2)).mean() / 64.0 / a.spp
-    report("perfect balance inside a tile (lower bound)", ideal)
+    report("perfect balance inside a tile (lower bound) = the useful iterations", useful)
+
+    # K = 2 with what the swap costs: a lane whose first ray has ended gets its second one at a swap event (save the ended
+    # ray's result, load the parked ray: ~25-35 instructions for the whole wave = 0.3-0.5 of a 75-instruction iteration);
+    # events at fixed iteration counts plus a last one when every first ray has ended
+    def k2_events(first, second, times, cswap):
+        tot = 0.0
+        for t in range(0, first.shape[0], 4):                  # every 4th tile is plenty
+            a1, b1 = first[t].astype(float), second[t].astype(float)
+            cur = np.where(a1 > 0, a1, b1)
+            sec = np.where((a1 > 0) & (b1 > 0), b1, 0.0)
+            end, started = cur.copy(), sec <= 0
+            for tt in list(times) + [None]:
+                if tt is None:
+                    tt = end[~started].max() if (~started).any() else 0.0
+                sw = (~started) & (end <= tt)
+                if not sw.any():
+                    continue
+                end[end > tt] += cswap
+                end[sw] = tt + cswap + sec[sw]
+                started |= sw
+            tot += end.max()
+        return tot / len(range(0, first.shape[0], 4))
+
+    if a.spp >= 2:
+        print("K=2 on the GI / GI-shadow stages with the cost of the swap events (wave-iterations for two samples' stage):")
+        for k, n in ((2, "GI"), (3, "GI shadow")):
+            first, second = tr[:, :, 0, k], tr[:, :, 1, k]
+            now = (first.max(axis=1) + second.max(axis=1))[::4].mean()
+            free = (first + second).max(axis=1)[::4].mean()
+            line = f"  {n:10s} now {now:6.2f}  free swaps {free:6.2f} ({(free / now - 1) * 100:+.1f} %)"
+            for times in ([], [16], [20], [16, 22], [12, 16, 20, 24]):
+                for cs in (0.3, 0.5):
+                    r = k2_events(first, second, times, cs)
+                    line += f" | events {times or 'end only'} c={cs}: {(r / now - 1) * 100:+.1f} %"
+            print(line)
 
 
 if __name__ == "__main__":
