@@ -64,7 +64,7 @@ inline std::vector<uint8_t> loadBMP(const std::string& path, uint32_t* width = n
     const uint32_t off = u32(10), bpp = u16(28), comp = u32(30);
     const int32_t w = (int32_t)u32(18), hs = (int32_t)u32(22);
     const uint32_t h = (uint32_t)(hs < 0 ? -hs : hs);
-    if (w <= 0 || h == 0 || (bpp != 24 && bpp != 32) || (comp != 0 && !(comp == 3 && bpp == 32)))
+    if (w <= 0 || w > 16384 || h == 0 || h > 16384 || (bpp != 24 && bpp != 32) || (comp != 0 && !(comp == 3 && bpp == 32)))
         throw std::runtime_error("loadBMP: only uncompressed 24 / 32 bpp is supported: " + path);
     const size_t stride = ((size_t)w * (bpp / 8) + 3) & ~(size_t)3;
     if (d.size() < off + stride * h) throw std::runtime_error("loadBMP: truncated file: " + path);

@@ -36,10 +36,12 @@ def load_bmp(path):
     off = struct.unpack_from("<I", d, 10)[0]
     w, hs, _planes, bpp, comp = struct.unpack_from("<iiHHI", d, 18)
     h = abs(hs)
-    if w <= 0 or h == 0 or bpp not in (24, 32) or not (comp == 0 or (comp == 3 and bpp == 32)):
+    if not (0 < w <= 16384 and 0 < h <= 16384) or bpp not in (24, 32) or not (comp == 0 or (comp == 3 and bpp == 32)):
         raise ValueError(f"{path}: only uncompressed 24 / 32 bpp is supported")
     bpx = bpp // 8
     stride = (w * bpx + 3) & ~3
+    if len(d) < off + stride * h:
+        raise ValueError(f"{path}: truncated file")
     out = np.zeros((h, w, 3), np.uint8)
     for row in range(h):
         y = row if hs < 0 else h - 1 - row

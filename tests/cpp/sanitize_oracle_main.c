@@ -25,4 +25,17 @@ int main(void){
   for(int i=0;i<6;i++) printf("%u/%u ",out[i].hit,out[i].complexity); printf("\n");
   uint8_t cells[8*8*8]; memset(cells,0,512); cells[3*64+4*8+5]=1;
   float go[3]={0.5f,0.5f,0.5f},gd[3]={0.4f,0.5f,0.6f}; orc_hit gh; orc_grid_cast_ray(cells,8,8,8,go,gd,&gh); printf("grid %u %u\n",gh.hit,gh.complexity);
+  /* round 2 surface: present chain (all medians, odd sizes), the reference-decomposition entries, the trace hooks */
+  { const uint32_t W=37,H=23,OW=50,OH=31; uint8_t* im=malloc(W*H*4); uint8_t* den=calloc(W*H*4,1); uint8_t* win=malloc(OW*OH*4);
+    for(uint32_t i=0;i<W*H*4;i++) im[i]=(uint8_t)(i*37u+11u);
+    for(uint32_t m=0;m<3;m++){ orc_present(im,den,W,H,0.1f,m==0?0u:(m==1?3u:5u),win,OW,OH); orc_present(im,den,W,H,0.0f,0u,NULL,0,0); }
+    printf("present %u %u\n",win[0],den[5]); free(im);free(den);free(win); }
+  p.use_samples=1;p.checker_parity=-1;p.rng_mode=0;p.gi_bounces=1;p.width=99;p.height=57;
+  { uint8_t* im=calloc(99*57*4,1); uint32_t* ac=calloc(99*57*4,4); orc_frame_stats s2;
+    orc_render_frame_areas16(nodes,depth,tex,tex,&cam,&p,im,ac,&s2);
+    orc_area_frame af; memset(&af,0,sizeof(af)); af.nodes=nodes;af.depth=depth;af.tex_top=tex;af.tex_side=tex;af.cam=&cam;af.params=&p;af.image=im;af.accum=ac;
+    for(uint32_t t=0;t<17;t++) orc_area_job(t,16,&af);
+    uint16_t* tr=calloc(99*57*ORC_TRACE_RAYS,2); uint8_t* ops=calloc((size_t)99*57*ORC_TRACE_RAYS*64,1);
+    orc_render_frame_optrace(nodes,depth,tex,tex,&cam,&p,2,tr,ops,64);
+    printf("areas %lu trace %u\n",(unsigned long)s2.rays,tr[0]); free(im);free(ac);free(tr);free(ops); }
   orc_free(nodes); orc_svo_free(s); free(h);free(img);free(acc);free(prim); return 0; }
