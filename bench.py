@@ -221,6 +221,10 @@ def main():
                     help="N > 1: how the RGBA8 row-block shards meet: 'all' = RCCL all-gather (every rank ends up with the "
                          "frame), 'root' = RCCL gather to rank 0, the presenting rank (north_star / SURVEY 8e: 1/N of the "
                          "bytes on the wire)")
+    ap.add_argument("--fused", default="auto", choices=["auto", "0", "1"],
+                    help="resolve + pack + reset inside the frame kernel (vrc_render_frame_resolved) instead of a second kernel; "
+                         "auto = from four GPUs on, where a rank's frame is short enough for the second launch to show "
+                         "(tools/resolve_cost.py: 233 -> 206 us per frame at N = 8, 398 -> 389 at N = 4, no gain at N <= 2)")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra measurements (2-bounce extension)")
     ap.add_argument("--tuning", default="", help="blocks_per_cu,refill_threshold,chunk")
     ap.add_argument("--kernel", type=int, default=2,
@@ -296,6 +300,7 @@ def main():
     # next frame's launch, like the all-gather of frame i overlaps the render of frame i + 1.  Frames stay independent
     # and complete in order; F = 1 is the plain one-stream loop.
     F = args.inflight if args.inflight > 0 else (2 if world <= 2 else 4)
+    fused = world >= 4 if args.fused == "auto" else args.fused == "1"
 
     def make_renderer():
         r = vrc.RayCaster(svo, (W, H))
@@ -349,13 +354,18 @@ def main():
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
             e0.record(ts)
-            if dist_on:
+            if dist_on and fused:
+                rc.renderFrameResolved(cam, spp=spp, dst_ptr=mine[slot].data_ptr(), stream=stream, row_block=ROW_BLOCK, shard_index=rank, shard_count=world)
+            elif dist_on:
                 rc.renderFrame(cam, spp=spp, stream=stream, row_block=ROW_BLOCK, shard_index=rank, shard_count=world)
+            elif fused:
+                rc.renderFrameResolved(cam, spp=spp, stream=stream)
             else:
                 rc.renderFrame(cam, spp=spp, stream=stream)
             e1.record(ts)
             if dist_on:
-                rc.resolveShard(ROW_BLOCK, rank, world, mine[slot].data_ptr(), reset=True, stream=stream)
+                if not fused:                                      # (fused: resolved, packed and reset by the frame kernel)
+                    rc.resolveShard(ROW_BLOCK, rank, world, mine[slot].data_ptr(), reset=True, stream=stream)
                 if backend == "nccl":
                     # RCCL over xGMI: RGBA8 row-block shards; enqueued behind the resolve, runs beside the next render.
                     # --gather all: all-gather; --gather root: rank 0 receives every shard straight into its place of
@@ -368,7 +378,7 @@ def main():
                     gathered[slot].copy_(torch.cat(parts))
                     state["pending"][slot] = "sync"
                 state["last_slot"] = slot
-            else:
+            elif not fused:
                 rc.resolveShard(reset=True, stream=stream)
         state["i"] += 1
         if timed:
@@ -573,7 +583,7 @@ def main():
                        "loop_iterations_per_frame": steps_sum // args.steps,
                        "camera_pitch": args.pitch, "lsvo_nodes": svo.n_nodes,
                        "lsvo_gpu_build_ms": round(svo.build_ms, 3), "lsvo_gpu_build_call_ms": round(build_call_ms, 3),
-                       "frames_in_flight": F, "host_enqueue_us_per_step": round(host_enqueue_us, 1), "sharding": f"{ROW_BLOCK}-row blocks round-robin over {world} GPU(s)"
+                       "frames_in_flight": F, "resolve_fused_into_frame_kernel": fused, "host_enqueue_us_per_step": round(host_enqueue_us, 1), "sharding": f"{ROW_BLOCK}-row blocks round-robin over {world} GPU(s)"
                        + (f", RCCL {'gather to rank 0' if args.gather == 'root' else 'all-gather'} of RGBA8 shards" if dist_on else ""),
                        "ranks_in_process_group": (dist.get_world_size() if dist_on else 1),
                        "gathered_frame_equals_unsharded": verified},

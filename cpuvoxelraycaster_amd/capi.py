@@ -71,6 +71,7 @@ SYMBOLS = {
     "vrc_renderer_create": (_int, [_vp, _u32, _u32, C.POINTER(_vp)]),
     "vrc_renderer_destroy": (_int, [_vp]),
     "vrc_render_frame": (_int, [_vp, C.POINTER(Camera), C.POINTER(FrameParams), _vp]),
+    "vrc_render_frame_resolved": (_int, [_vp, C.POINTER(Camera), C.POINTER(FrameParams), _vp, _vp]),
     "vrc_renderer_set_primary_capture": (_int, [_vp, _vp]),
     "vrc_samples_to_image": (_int, [_vp, _vp]),
     "vrc_reset_samples": (_int, [_vp, _vp]),

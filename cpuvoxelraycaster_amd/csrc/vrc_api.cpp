@@ -98,7 +98,10 @@ struct vrc_renderer {
     void* d_accum = nullptr;  // 4 x u32 per pixel
     void* d_stats = nullptr;  // VRC_STATS_BYTES of counter slots, then VRC_QUEUE_BYTES of work-queue heads
     vrc_hit* d_prim = nullptr;
-    bool queue_clean = false;   // the heads were zeroed by vrc_resolve_shard(reset) after the last frame launch
+    // two sets of work-queue heads: a stage-synchronous launch takes its units from one set and zeroes the other for the
+    // launch after it; queue_zero[s] = set s is known to hold zeros when the next launch reaches it
+    bool queue_zero[2] = {false, false};
+    uint32_t* d_tile_done = nullptr;   // one arrival counter per 8 x 8 tile (fused resolve), zero between frames
     Tuning tuning;      // snapshot of the process defaults at creation; vrc_renderer_set_* change it
 };
 
@@ -423,15 +426,20 @@ extern "C" int vrc_renderer_create(const vrc_scene* s, uint32_t width, uint32_t 
     const uint64_t n = (uint64_t)width * height;
     hipError_t e = hipMalloc(&r->d_image, n * 4);
     if (e == hipSuccess) e = hipMalloc(&r->d_accum, n * 16);
-    if (e == hipSuccess) e = hipMalloc(&r->d_stats, vrc::VRC_STATS_BYTES + vrc::VRC_QUEUE_BYTES);
+    const uint64_t n_tiles = (uint64_t)((width + 7u) / 8u) * ((height + 7u) / 8u);
+    if (e == hipSuccess) e = hipMalloc(&r->d_stats, vrc::VRC_STATS_BYTES + 2 * vrc::VRC_QUEUE_BYTES);
+    if (e == hipSuccess) e = hipMalloc((void**)&r->d_tile_done, n_tiles * 4);
     if (e == hipSuccess) e = hipMemset(r->d_accum, 0, n * 16);
-    if (e == hipSuccess) e = hipMemset(r->d_stats, 0, vrc::VRC_STATS_BYTES + vrc::VRC_QUEUE_BYTES);
+    if (e == hipSuccess) e = hipMemset(r->d_stats, 0, vrc::VRC_STATS_BYTES + 2 * vrc::VRC_QUEUE_BYTES);
+    if (e == hipSuccess) e = hipMemset(r->d_tile_done, 0, n_tiles * 4);
+    r->queue_zero[0] = r->queue_zero[1] = true;
     if (e == hipSuccess) e = vrc::launch_fill_u32(r->d_image, 0xff000000u, n, nullptr);  // sf::Image::create: opaque black
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) {
         if (r->d_image) (void)hipFree(r->d_image);
         if (r->d_accum) (void)hipFree(r->d_accum);
         if (r->d_stats) (void)hipFree(r->d_stats);
+        if (r->d_tile_done) (void)hipFree(r->d_tile_done);
         delete r;
         return fail(e == hipErrorOutOfMemory ? VRC_ERR_OOM : VRC_ERR_HIP, "vrc_renderer_create: %s", hipGetErrorString(e));
     }
@@ -446,6 +454,7 @@ extern "C" int vrc_renderer_destroy(vrc_renderer* r)
     (void)hipFree(r->d_image);
     (void)hipFree(r->d_accum);
     (void)hipFree(r->d_stats);
+    (void)hipFree(r->d_tile_done);
     delete r;
     return VRC_OK;
 }
@@ -462,7 +471,31 @@ extern "C" int vrc_renderer_set_primary_capture(vrc_renderer* r, vrc_hit* prim_d
     return VRC_OK;
 }
 
+namespace {
+// fused: resolve + pack + reset in the frame kernel (vrc_render_frame_resolved); dst: packed shard rows or NULL
+int render_impl(vrc_renderer* r, const vrc_camera* cam, const vrc_frame_params* p, bool fused, void* dst, void* stream);
+}
+
 extern "C" int vrc_render_frame(vrc_renderer* r, const vrc_camera* cam, const vrc_frame_params* p, void* stream)
+{
+    return render_impl(r, cam, p, false, nullptr, stream);
+}
+
+// vrc_render_frame + vrc_resolve_shard(row_block, shard_index, shard_count, dst, reset = 1) as ONE launch where the frame
+// kernel can do it (stage-synchronous kernel, sample mode, no checkerboard), as those two calls otherwise.
+extern "C" int vrc_render_frame_resolved(vrc_renderer* r, const vrc_camera* cam, const vrc_frame_params* p, void* dst_dev, void* stream)
+{
+    if (!r || !cam || !p) return fail(VRC_ERR_INVALID, "vrc_render_frame_resolved: null argument");
+    if (!p->use_samples) return fail(VRC_ERR_INVALID, "vrc_render_frame_resolved: needs use_samples (there is nothing to resolve otherwise)");
+    if (r->tuning.kernel == VRC_KERNEL_SYNC && p->checker_parity < 0) return render_impl(r, cam, p, true, dst_dev, stream);
+    int rc = render_impl(r, cam, p, false, nullptr, stream);
+    if (rc) return rc;
+    const bool sharded = p->row_block && p->shard_count > 1;
+    return vrc_resolve_shard(r, sharded ? p->row_block : 0u, sharded ? p->shard_index : 0u, sharded ? p->shard_count : 1u, dst_dev, 1, stream);
+}
+
+namespace {
+int render_impl(vrc_renderer* r, const vrc_camera* cam, const vrc_frame_params* p, bool fused, void* dst, void* stream)
 {
     if (!r || !cam || !p) return fail(VRC_ERR_INVALID, "vrc_render_frame: null argument");
     if (p->gi_bounces > 2) return fail(VRC_ERR_INVALID, "vrc_render_frame: gi_bounces %u > 2 not supported", p->gi_bounces);
@@ -507,8 +540,25 @@ extern "C" int vrc_render_frame(vrc_renderer* r, const vrc_camera* cam, const vr
     a.chunk = tuning.chunk;
     a.refill_threshold = tuning.refill_threshold;
     if (a.n_items == 0) return VRC_OK;
-    if (!r->queue_clean) HIP_TRY(hipMemsetAsync(a.queue, 0, vrc::VRC_QUEUE_BYTES, st));
-    r->queue_clean = false;
+    {
+        uint32_t* sets[2] = {a.queue, a.queue + vrc::VRC_QUEUE_BYTES / 4};
+        if (tuning.kernel == VRC_KERNEL_SYNC) {
+            // take a set that is known to be zero (memset one if neither is: first use after another kernel); the launch
+            // zeroes the other set, so the next launch finds its queue ready without a memset or a kernel in between
+            const int use = r->queue_zero[0] ? 0 : (r->queue_zero[1] ? 1 : 0);
+            if (!r->queue_zero[use]) HIP_TRY(hipMemsetAsync(sets[use], 0, vrc::VRC_QUEUE_BYTES, st));
+            a.queue = sets[use];
+            a.queue_other = sets[1 - use];
+            r->queue_zero[use] = false;
+            r->queue_zero[1 - use] = true;
+        } else {
+            if (!r->queue_zero[0]) HIP_TRY(hipMemsetAsync(sets[0], 0, vrc::VRC_QUEUE_BYTES, st));
+            r->queue_zero[0] = false;
+        }
+    }
+    a.fused_resolve = fused ? 1u : 0u;
+    a.tile_done = r->d_tile_done;
+    a.resolve_dst = (uint32_t*)dst;
     uint64_t want = (items + VRC_RENDER_BLOCK - 1) / VRC_RENDER_BLOCK;
     // k_render_tile: (depth-1)*2 KiB of stacks + 21 KiB of job pools + 1.5 KiB of tables per workgroup
     // (38.5 KiB at depth 9): at most 4 fit a CU's 160 KiB; 120 VGPRs allow 4 waves per SIMD as well
@@ -560,6 +610,7 @@ extern "C" int vrc_render_frame(vrc_renderer* r, const vrc_camera* cam, const vr
     HIP_TRY(vrc::launch_render(a, grid, (int)tuning.kernel, st));
     return VRC_OK;
 }
+}  // namespace
 
 extern "C" int vrc_samples_to_image(vrc_renderer* r, void* stream)
 {
@@ -671,7 +722,7 @@ extern "C" int vrc_resolve_shard(vrc_renderer* r, uint32_t row_block, uint32_t s
     HIP_TRY(vrc::launch_resolve_shard(r->d_accum, r->d_image, r->width, r->height, row_block, shard_index, shard_count,
                                       shard_slots(r->height, row_block, shard_count), dst_dev, reset ? 1u : 0u, queue,
                                       (hipStream_t)stream));
-    if (reset) r->queue_clean = true;
+    if (reset) r->queue_zero[0] = true;     // k_resolve_shard zeroes the first set's heads in the same pass
     return VRC_OK;
 }
 

@@ -41,7 +41,7 @@ constexpr uint32_t VRC_STAT_SLOTS = 1024;      // 32-byte slots, slot = workgrou
 constexpr uint32_t VRC_QUEUE_HEADS = 8;
 constexpr uint32_t VRC_QUEUE_STRIDE = 1024;    // u32 between heads (4 KiB: separate L2 channels)
 constexpr uint32_t VRC_STATS_BYTES = VRC_STAT_SLOTS * 32u;
-constexpr uint32_t VRC_QUEUE_BYTES = VRC_QUEUE_HEADS * VRC_QUEUE_STRIDE * 4u;
+constexpr uint32_t VRC_QUEUE_BYTES = VRC_QUEUE_HEADS * VRC_QUEUE_STRIDE * 4u;   // one set of heads; a renderer has two
 
 // by-value kernel argument of k_render
 struct FrameArgs {
@@ -59,6 +59,15 @@ struct FrameArgs {
     uint32_t sample_chunk;    // k_render_sync: samples per work unit (0 = all spp in one unit)
     uint32_t sample_chunk_tail, tail_tiles;   // ... and for the last `tail_tiles` tiles (0 = same chunk)
     uint32_t checker_wide;    // k_render_sync, checkerboard frames: tiles are 16 x 8 pixels, every lane takes a selected pixel
+    // k_render_sync*: the heads of the renderer's OTHER queue set, zeroed by this launch for the next one (the two sets
+    // alternate, so no launch needs a memset or another kernel to find its queue at zero); NULL = leave it alone
+    uint32_t* queue_other;
+    // fused resolve (vrc_render_frame_resolved): when a tile's last work unit has added its samples it turns the tile's
+    // sums into RGBA8 -- image, and resolve_dst (packed shard rows, may be NULL) -- and leaves the accumulators at zero:
+    // samples_to_image + pack_shard + reset_samples without a second kernel.  tile_done: one arrival counter per tile.
+    uint32_t fused_resolve;
+    uint32_t* tile_done;
+    uint32_t* resolve_dst;
     vrc_camera cam;
     vrc_frame_params p;
 };

@@ -964,6 +964,7 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
     const uint32_t n_tiles = a.n_items >> 6;
     const bool sharded = a.p.row_block && a.p.shard_count > 1u;
     constexpr bool pinhole = PINHOLE;     // see launch_render for the host's predicate
+    if (a.queue_other && blockIdx.x == 0u && threadIdx.x < VRC_QUEUE_HEADS) a.queue_other[threadIdx.x * VRC_QUEUE_STRIDE] = 0u;
     // Work unit = (tile, chunk of `sample_chunk` samples).  With few tiles per GPU (multi-GPU shards)
     // the host splits a pixel's samples over several units so every wave still gets several units;
     // the accumulators are then updated with integer atomics (exact, order-independent).
@@ -1199,18 +1200,58 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
 #endif
             }
         }
-        if (valid && a.p.use_samples) {                                              // raycaster.hpp:87-90
-            if (chunks_per_tile == 1u) {
-                uint4* ap = reinterpret_cast<uint4*>(a.accum) + pix;
-                uint4 v = *ap;
-                v.x += acc_r; v.y += acc_g; v.z += acc_b; v.w += spp;
-                *ap = v;
-            } else {
-                // two 64-bit adds per pixel: (r, g) and (b, count) as pairs of u32 -- a sum never carries out of its
-                // low word (sums < 2^32, as the accumulator format requires), so each half adds independently
+        if (a.p.use_samples && !a.fused_resolve) {                                   // raycaster.hpp:87-90
+            if (valid) {
+                if (chunks_per_tile == 1u) {
+                    uint4* ap = reinterpret_cast<uint4*>(a.accum) + pix;
+                    uint4 v = *ap;
+                    v.x += acc_r; v.y += acc_g; v.z += acc_b; v.w += spp;
+                    *ap = v;
+                } else {
+                    // two 64-bit adds per pixel: (r, g) and (b, count) as pairs of u32 -- a sum never carries out of its
+                    // low word (sums < 2^32, as the accumulator format requires), so each half adds independently
+                    unsigned long long* ap = reinterpret_cast<unsigned long long*>(a.accum + 4ull * pix);
+                    atomicAdd(ap + 0, (unsigned long long)acc_r | ((unsigned long long)acc_g << 32));
+                    atomicAdd(ap + 1, (unsigned long long)acc_b | ((unsigned long long)(s_end - s_begin) << 32));
+                }
+            }
+        } else if (a.p.use_samples) {
+            // Fused resolve: samples_to_image (raycaster.hpp:94-103: uint8(sum / count)), the shard pack and resetSamples
+            // (:105-116) for this tile, done by whichever of the tile's work units finishes last.  The accumulators are
+            // zero between frames in this mode, so a tile whose samples are all in one unit never touches them.
+            const uint32_t compact_row = ty * 8u + (lane >> 3);               // row inside this shard's packed buffer
+            bool resolve = true;
+            uint32_t sum_r = acc_r, sum_g = acc_g, sum_b = acc_b, count = s_end - s_begin;
+            if (chunks_per_tile != 1u) {
                 unsigned long long* ap = reinterpret_cast<unsigned long long*>(a.accum + 4ull * pix);
-                atomicAdd(ap + 0, (unsigned long long)acc_r | ((unsigned long long)acc_g << 32));
-                atomicAdd(ap + 1, (unsigned long long)acc_b | ((unsigned long long)(s_end - s_begin) << 32));
+                if (valid) {
+                    atomicAdd(ap + 0, (unsigned long long)acc_r | ((unsigned long long)acc_g << 32));
+                    atomicAdd(ap + 1, (unsigned long long)acc_b | ((unsigned long long)(s_end - s_begin) << 32));
+                }
+                // Every lane's adds are performed at the memory side before this unit counts as arrived; the counter add
+                // is a device-scope atomic too, and the last arriver takes the sums with device-scope exchanges -- never
+                // with loads: the 128-byte line of a pixel's sums also holds neighbours' (of another tile when the width
+                // is not a multiple of 8), and a line a load left in this XCD's L2 is not updated by other XCDs' adds
+                // (MI355X_MICROARCH.md, inter-workgroup visibility).  The exchange also leaves the zero resetSamples wants.
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                uint32_t arrived = 0u;
+                if (lane == 0u) arrived = atomicAdd(a.tile_done + tile, 1u) + 1u;
+                arrived = __builtin_amdgcn_readfirstlane(arrived);
+                resolve = arrived == chunks_per_tile;
+                if (resolve) {
+                    if (valid) {
+                        const unsigned long long rg = atomicExch(ap + 0, 0ull);
+                        const unsigned long long bc = atomicExch(ap + 1, 0ull);
+                        sum_r = (uint32_t)rg; sum_g = (uint32_t)(rg >> 32); sum_b = (uint32_t)bc; count = (uint32_t)(bc >> 32);
+                    }
+                    if (lane == 0u) atomicExch(a.tile_done + tile, 0u);                           // ... and for the tile
+                }
+            }
+            if (resolve && valid) {
+                uint32_t c = 0xff000000u;
+                if (count) c |= (sum_r / count) | ((sum_g / count) << 8) | ((sum_b / count) << 16);
+                reinterpret_cast<uint32_t*>(a.image)[pix] = c;
+                if (a.resolve_dst) a.resolve_dst[(uint64_t)compact_row * W + px_x] = c;
             }
         }
     }

@@ -208,6 +208,13 @@ class RayCaster:
     def setSampleChunk(self, samples_per_unit):
         check(capi.load().vrc_renderer_set_sample_chunk(self._h, samples_per_unit))
 
+    def renderFrameResolved(self, camera, spp=1, dst_ptr=None, stream=None, row_block=0, shard_index=0, shard_count=1):
+        """renderFrame + resolveShard(..., reset=True) in one launch (vrc_render_frame_resolved): the frame's samples
+        rendered, resolved into the image (and the packed shard buffer dst_ptr), accumulators left at zero."""
+        p = self.params(spp, -1, row_block, shard_index, shard_count)
+        check(capi.load().vrc_render_frame_resolved(self._h, C.byref(camera), C.byref(p), ptr(dst_ptr), ptr(stream)))
+        self.frame_index += spp
+
     def setPrimaryCapture(self, dev_ptr):
         check(capi.load().vrc_renderer_set_primary_capture(self._h, ptr(dev_ptr)))
 

@@ -197,6 +197,15 @@ int vrc_renderer_destroy(vrc_renderer *r);
  * pixel, Camera::getRay + RayCaster::renderRay, `spp` times.  Adds to the
  * renderer's running vrc_frame_stats.  Asynchronous on `stream`. */
 int vrc_render_frame(vrc_renderer *r, const vrc_camera *cam, const vrc_frame_params *p, void *stream);
+/* vrc_render_frame followed by vrc_resolve_shard(r, p->row_block, p->shard_index, p->shard_count, dst_dev, reset = 1)
+ * -- i.e. the swarm lambda, samples_to_image() and resetSamples() of one progressive frame (main.cpp:139-158,
+ * raycaster.hpp:94-116) -- as ONE launch: the tile's last work unit turns the tile's sample sums into RGBA8 (into the
+ * image and, if dst_dev != NULL, into the packed shard buffer) and leaves the accumulators at zero.  Needs
+ * p->use_samples and accumulators that are zero on entry (after creation, vrc_reset_samples, vrc_resolve_shard(reset)
+ * or a previous call of this function); same image, same shard rows, same counters as the two calls.  Rows of dst_dev
+ * that correspond to no image row (padding of the last row block / slot) are left untouched.  Frame kernels or modes
+ * that cannot fuse (checkerboard, vrc_set_kernel 0 / 1) run the two calls instead. */
+int vrc_render_frame_resolved(vrc_renderer *r, const vrc_camera *cam, const vrc_frame_params *p, void *dst_dev, void *stream);
 /* Optional: also record the primary-ray HitPoint of sample 0 per pixel into
  * prim_dev (device memory, width*height vrc_hit) during the next frames; NULL disables. */
 int vrc_renderer_set_primary_capture(vrc_renderer *r, vrc_hit *prim_dev);
