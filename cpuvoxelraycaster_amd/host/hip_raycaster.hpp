@@ -206,6 +206,22 @@ public:
         frame_index_ += spp;
     }
 
+    // One progressive frame in one launch: renderFrame (sample mode, every pixel) + samples_to_image + resetSamples, the
+    // resolved rows also written to `shard_dev` (device, may be null) as the multi-GPU exchange expects them.
+    void renderFrameResolved(const CameraState& camera, uint32_t spp, void* shard_dev = nullptr, void* stream = nullptr)
+    {
+        vrc_frame_params p{};
+        p.row_block = row_block_; p.shard_index = shard_index_; p.shard_count = shard_count_;
+        p.light_position[0] = light_.x; p.light_position[1] = light_.y; p.light_position[2] = light_.z;
+        p.use_gi = use_gi; p.use_samples = 1;
+        p.shadow_samples = 0; p.gi_bounces = 1;
+        p.checker_parity = -1; p.spp = spp;
+        p.seed = seed; p.frame_index = frame_index_;
+        const vrc_camera c = camera.to_abi();
+        check(vrc_render_frame_resolved(r_, &c, &p, shard_dev, stream), "vrc_render_frame_resolved");
+        frame_index_ += spp;
+    }
+
     void samples_to_image(void* stream = nullptr) { check(vrc_samples_to_image(r_, stream), "vrc_samples_to_image"); }   // raycaster.hpp:94
     void resetSamples(void* stream = nullptr) { check(vrc_reset_samples(r_, stream), "vrc_reset_samples"); }            // raycaster.hpp:105
     // samples_to_image for this shard's rows, written into `shard_dev` (device, vrc_shard_bytes) as the all-gather

@@ -69,6 +69,17 @@ int main(int argc, char** argv)
             std::vector<uint8_t> composed((size_t)W * H * 4);
             if (hipMemcpy(composed.data(), full, composed.size(), hipMemcpyDeviceToHost) != hipSuccess) return 3;
             std::printf("sharded equal=%d\n", composed == img ? 1 : 0);
+            // the same three shards, each through ONE launch (renderFrameResolved = render + resolve + reset fused)
+            for (uint32_t k = 0; k < N; ++k) {
+                vrc_host::HipRayCaster part(lsvo, W, H);
+                part.setLightPosition({-200.0f / 512.0f + 1.0f, -1000.0f / 512.0f + 1.0f, -300.0f / 512.0f + 1.0f});
+                part.use_gi = true; part.use_samples = true;
+                part.setShard(RB, k, N);
+                part.renderFrameResolved(cam, 2, (char*)gathered + nbytes * k);
+            }
+            vrc_host::check(vrc_unpack_shards(gathered, W, H, RB, N, full, nullptr), "vrc_unpack_shards");
+            if (hipMemcpy(composed.data(), full, composed.size(), hipMemcpyDeviceToHost) != hipSuccess) return 3;
+            std::printf("sharded fused equal=%d\n", composed == img ? 1 : 0);
             (void)hipFree(gathered); (void)hipFree(full);
         }
     } catch (const std::exception& e) {

@@ -35,6 +35,7 @@ def test_cpp_host_adapter_matches_oracle(built, heights, textures, tmp_path):
     f = re.search(r"frame sum=(\d+) fnv=([0-9a-f]+) rays=(\d+) steps=(\d+)", out.stdout)
     assert m and f, out.stdout
     assert "sharded equal=1" in out.stdout, out.stdout      # setShard + resolveShard + vrc_unpack_shards == unsharded
+    assert "sharded fused equal=1" in out.stdout, out.stdout   # ... and with renderFrameResolved (one launch per shard)
     # oracle: same autofocus ray, same frame
     S = float(1 << depth)
     rot = O.make_rotation(0.0, -0.5)

@@ -106,23 +106,35 @@ def main():
             oimg = oacc = None
             rr = ss = 0
             fi = 0
+            # half of the sample-mode frames without checkerboard go through the fused call (render + resolve + reset in
+            # one launch): every call's image must be the oracle's resolve of THAT call's samples, accumulators zero after
+            fused = bool(use_samples and not checker and rng.integers(0, 2))
+            ok = True
             for f in range(nfr):
                 par = (f % 2) if checker else -1
-                rc.renderFrame(cam, spp=spp, checker_parity=par, row_block=row_block, shard_index=shard_index, shard_count=shard_count)
+                if fused:
+                    rc.renderFrameResolved(cam, spp=spp, row_block=row_block, shard_index=shard_index, shard_count=shard_count)
+                    oacc = None
+                else:
+                    rc.renderFrame(cam, spp=spp, checker_parity=par, row_block=row_block, shard_index=shard_index, shard_count=shard_count)
                 for s in range(spp):
                     p = O.make_params(W, H, light, use_gi=int(rc.use_gi), use_samples=use_samples, shadow_samples=rc.shadow_samples,
                                       gi_bounces=rc.gi_bounces, checker_parity=par, seed=rc.seed, frame_index=fi,
                                       row_block=row_block, shard_index=shard_index, shard_count=shard_count)
                     oimg, oacc, _, st = O.render_frame(nodes, depth, top, side, ocam, p, image=oimg, accum=oacc, threads=16)
                     rr += st.rays; ss += st.sum_complexity; fi += 1
+                if fused:
+                    mine = oacc[..., 3] > 0                                 # this shard's pixels
+                    ok = ok and np.array_equal(rc.readImage()[mine], O.samples_to_image(oacc)[mine]) and not rc.readAccum().any()
             st = rc.stats()
-            ok = (st.rays, st.sum_complexity) == (rr, ss)
-            ok = ok and (np.array_equal(rc.readAccum(), oacc) if use_samples else np.array_equal(rc.readImage(), oimg))
+            ok = ok and (st.rays, st.sum_complexity) == (rr, ss)
+            if not fused:
+                ok = ok and (np.array_equal(rc.readAccum(), oacc) if use_samples else np.array_equal(rc.readImage(), oimg))
             frames += 1
             rays_total += rr
             if not ok:
                 print("FRAME MISMATCH", it, dict(depth=depth, W=W, H=H, kernel=kernel, spp=spp, gi=rc.use_gi, samples=use_samples,
-                                                 checker=checker, shard=(row_block, shard_index, shard_count))); bad += 1
+                                                 checker=checker, fused=fused, shard=(row_block, shard_index, shard_count))); bad += 1
             vrc.capi.check(L.vrc_set_kernel(2)); vrc.capi.check(L.vrc_set_sample_chunk(0))
     print(f"fuzz: {it} cases ({frames} frames), {rays_total} rays compared, {bad} mismatches, {time.time() - t0:.0f} s")
     sys.exit(1 if bad else 0)
