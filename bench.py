@@ -223,8 +223,8 @@ def main():
                          "bytes on the wire)")
     ap.add_argument("--fused", default="auto", choices=["auto", "0", "1"],
                     help="resolve + pack + reset inside the frame kernel (vrc_render_frame_resolved) instead of a second kernel; "
-                         "auto = from four GPUs on, where a rank's frame is short enough for the second launch to show "
-                         "(tools/resolve_cost.py: 233 -> 206 us per frame at N = 8, 398 -> 389 at N = 4, no gain at N <= 2)")
+                         "auto = on more than four GPUs, where a rank's frame is short enough for the second launch to show "
+                         "(tools/resolve_cost.py: 227 -> 204 us per frame at N = 8, level at N = 4, a loss of 2-3 % at N <= 2)")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra measurements (2-bounce extension)")
     ap.add_argument("--tuning", default="", help="blocks_per_cu,refill_threshold,chunk")
     ap.add_argument("--kernel", type=int, default=2,
@@ -300,7 +300,7 @@ def main():
     # next frame's launch, like the all-gather of frame i overlaps the render of frame i + 1.  Frames stay independent
     # and complete in order; F = 1 is the plain one-stream loop.
     F = args.inflight if args.inflight > 0 else (2 if world <= 2 else 4)
-    fused = world >= 4 if args.fused == "auto" else args.fused == "1"
+    fused = world > 4 if args.fused == "auto" else args.fused == "1"
 
     def make_renderer():
         r = vrc.RayCaster(svo, (W, H))

@@ -936,7 +936,7 @@ __device__ __forceinline__ uint32_t albedo_of(const uint8_t* tex, const Hit& h)
 // Then a pixel's camera ray is the same for every sample, and so are its primary hit, albedo and shadow ray(s): a work
 // unit sets them up ONCE and walks them once per sample of the unit (every ray the reference casts is still walked and
 // counted; only the identical arithmetic around the walks is not repeated).  The per-sample work is the GI pair.
-template <bool PINHOLE, bool ONE_BOUNCE>
+template <bool PINHOLE, bool ONE_BOUNCE, bool FUSED>
 __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
 {
     extern __shared__ uint2 lds_dyn[];   // [depth-1][256] stack | 1536 B textures
@@ -964,7 +964,13 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
     const uint32_t n_tiles = a.n_items >> 6;
     const bool sharded = a.p.row_block && a.p.shard_count > 1u;
     constexpr bool pinhole = PINHOLE;     // see launch_render for the host's predicate
-    if (a.queue_other && blockIdx.x == 0u && threadIdx.x < VRC_QUEUE_HEADS) a.queue_other[threadIdx.x * VRC_QUEUE_STRIDE] = 0u;
+    // (arguments used once per launch or per work unit are read from the kernel-argument segment where they are needed
+    // rather than held in SGPRs throughout: the kernel is at its register budget)
+    const volatile FrameArgs* ka = (const volatile FrameArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    if (blockIdx.x == 0u && threadIdx.x < VRC_QUEUE_HEADS) {
+        uint32_t* const other = ka->queue_other;
+        if (other) other[threadIdx.x * VRC_QUEUE_STRIDE] = 0u;
+    }
     // Work unit = (tile, chunk of `sample_chunk` samples).  With few tiles per GPU (multi-GPU shards)
     // the host splits a pixel's samples over several units so every wave still gets several units;
     // the accumulators are then updated with integer atomics (exact, order-independent).
@@ -1200,7 +1206,7 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
 #endif
             }
         }
-        if (a.p.use_samples && !a.fused_resolve) {                                   // raycaster.hpp:87-90
+        if (a.p.use_samples && !FUSED) {                                             // raycaster.hpp:87-90
             if (valid) {
                 if (chunks_per_tile == 1u) {
                     uint4* ap = reinterpret_cast<uint4*>(a.accum) + pix;
@@ -1235,7 +1241,8 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
                 // (MI355X_MICROARCH.md, inter-workgroup visibility).  The exchange also leaves the zero resetSamples wants.
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 uint32_t arrived = 0u;
-                if (lane == 0u) arrived = atomicAdd(a.tile_done + tile, 1u) + 1u;
+                uint32_t* const tile_done = ka->tile_done;
+                if (lane == 0u) arrived = atomicAdd(tile_done + tile, 1u) + 1u;
                 arrived = __builtin_amdgcn_readfirstlane(arrived);
                 resolve = arrived == chunks_per_tile;
                 if (resolve) {
@@ -1244,14 +1251,15 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
                         const unsigned long long bc = atomicExch(ap + 1, 0ull);
                         sum_r = (uint32_t)rg; sum_g = (uint32_t)(rg >> 32); sum_b = (uint32_t)bc; count = (uint32_t)(bc >> 32);
                     }
-                    if (lane == 0u) atomicExch(a.tile_done + tile, 0u);                           // ... and for the tile
+                    if (lane == 0u) atomicExch(tile_done + tile, 0u);                             // ... and for the tile
                 }
             }
             if (resolve && valid) {
                 uint32_t c = 0xff000000u;
                 if (count) c |= (sum_r / count) | ((sum_g / count) << 8) | ((sum_b / count) << 16);
                 reinterpret_cast<uint32_t*>(a.image)[pix] = c;
-                if (a.resolve_dst) a.resolve_dst[(uint64_t)compact_row * W + px_x] = c;
+                uint32_t* const dst = ka->resolve_dst;
+                if (dst) dst[(uint64_t)compact_row * W + px_x] = c;
             }
         }
     }
@@ -1287,30 +1295,23 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
 // k_render_sync: any camera, the reference's one indirect bounce (k_render_sync2: the 2-bounce extension).
 // k_render_sync_pinhole: aperture +0 and one bounce -- the configuration the reference ships with and BASELINE's metric
 // is quoted on (k_render_sync_pinhole2: with the extension).  The bounce count is a compile-time fact in the one-bounce
-// kernels: gi_chain is straight-line code there, which is worth a third of the register spills.
-extern "C" __global__ void __launch_bounds__(VRC_RENDER_BLOCK, VRC_SYNC_MIN_WAVES)
-k_render_sync(const FrameArgs a)
-{
-    render_sync_body<false, true>(a);
-}
-
-extern "C" __global__ void __launch_bounds__(VRC_RENDER_BLOCK, VRC_SYNC_MIN_WAVES)
-k_render_sync2(const FrameArgs a)
-{
-    render_sync_body<false, false>(a);
-}
-
-extern "C" __global__ void __launch_bounds__(VRC_RENDER_BLOCK, VRC_SYNC_MIN_WAVES)
-k_render_sync_pinhole(const FrameArgs a)
-{
-    render_sync_body<true, true>(a);
-}
-
-extern "C" __global__ void __launch_bounds__(VRC_RENDER_BLOCK, VRC_SYNC_MIN_WAVES)
-k_render_sync_pinhole2(const FrameArgs a)
-{
-    render_sync_body<true, false>(a);
-}
+// kernels: gi_chain is straight-line code there, which is worth a third of the register spills.  The ..._resolved
+// kernels are the same four with the fused resolve (vrc_render_frame_resolved) compiled in; the plain ones do not
+// carry its code or its arguments' registers.
+#define VRC_SYNC_KERNEL(name, PINHOLE, ONE_BOUNCE, FUSED)                                          \
+    extern "C" __global__ void __launch_bounds__(VRC_RENDER_BLOCK, VRC_SYNC_MIN_WAVES) name(const FrameArgs a) \
+    {                                                                                              \
+        render_sync_body<PINHOLE, ONE_BOUNCE, FUSED>(a);                                           \
+    }
+VRC_SYNC_KERNEL(k_render_sync, false, true, false)
+VRC_SYNC_KERNEL(k_render_sync2, false, false, false)
+VRC_SYNC_KERNEL(k_render_sync_pinhole, true, true, false)
+VRC_SYNC_KERNEL(k_render_sync_pinhole2, true, false, false)
+VRC_SYNC_KERNEL(k_render_sync_resolved, false, true, true)
+VRC_SYNC_KERNEL(k_render_sync2_resolved, false, false, true)
+VRC_SYNC_KERNEL(k_render_sync_pinhole_resolved, true, true, true)
+VRC_SYNC_KERNEL(k_render_sync_pinhole2_resolved, true, false, true)
+#undef VRC_SYNC_KERNEL
 
 // ---------------------------------------------------------------------------
 // S4 sink + plumbing
@@ -1507,10 +1508,13 @@ hipError_t launch_render(const FrameArgs& a, uint32_t grid_blocks, int kernel, h
 #ifdef VRC_NO_PINHOLE_KERNEL   // A/B builds only
         pinhole = false;
 #endif
-        if (pinhole && a.p.gi_bounces <= 1u) hipLaunchKernelGGL(k_render_sync_pinhole, dim3(grid_blocks), dim3(VRC_RENDER_BLOCK), lds, st, a);
-        else if (pinhole) hipLaunchKernelGGL(k_render_sync_pinhole2, dim3(grid_blocks), dim3(VRC_RENDER_BLOCK), lds, st, a);
-        else if (a.p.gi_bounces <= 1u) hipLaunchKernelGGL(k_render_sync, dim3(grid_blocks), dim3(VRC_RENDER_BLOCK), lds, st, a);
-        else hipLaunchKernelGGL(k_render_sync2, dim3(grid_blocks), dim3(VRC_RENDER_BLOCK), lds, st, a);
+        const bool one = a.p.gi_bounces <= 1u, fused = a.fused_resolve != 0u;
+        void (*kernel_fn)(const FrameArgs) =
+            pinhole ? (one ? (fused ? k_render_sync_pinhole_resolved : k_render_sync_pinhole)
+                           : (fused ? k_render_sync_pinhole2_resolved : k_render_sync_pinhole2))
+                    : (one ? (fused ? k_render_sync_resolved : k_render_sync)
+                           : (fused ? k_render_sync2_resolved : k_render_sync2));
+        hipLaunchKernelGGL(kernel_fn, dim3(grid_blocks), dim3(VRC_RENDER_BLOCK), lds, st, a);
     }
     return hipGetLastError();
 }
