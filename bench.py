@@ -13,13 +13,15 @@ actually executed (counted by the kernel, equal to the oracle's count).
 Frames are independent, and a launch of the persistent frame kernel is mostly
 tail at its end: the last work units finish at latency speed while most of the
 chip idles (~4 % of a 1080p frame on one GPU, more on a multi-GPU shard).  So two
-renderers / streams alternate by default (`--inflight 2`; 4 from four GPUs on,
-where a rank's launch is only two or three work units deep): the end of one launch
-overlaps the start of the next frame, just as the exchange of frame i overlaps
-the renders after it.  ms_per_step is then the steady-state frame PERIOD (all K
-frames are complete inside the timed region) and can be shorter than one
-kernel's duration, which `roofline.kernel_ms` reports from events on the launch
-streams; `config.frames_in_flight` says which was used.  At N = 1 the plain
+three renderers / streams take turns by default (`--inflight 3`): the end of one
+launch overlaps the start of the next frames, just as the exchange of frame i
+overlaps the renders after it.  ms_per_step is then the steady-state frame PERIOD
+(all K frames are complete inside the timed region).  Overlapping launches share
+the chip, so the events around ONE launch (`roofline.kernel_ms_bracketed`, what
+rocprofv3 --stats reports as the kernel's average duration for this command) span
+about F frame periods; `roofline.kernel_ms`, the duration `achieved` is priced on,
+is the chip time per launch: HIP events from the first timed launch's start to the
+last one's end on the launch streams, divided by K.  At N = 1 the plain
 one-stream loop (`--inflight 1`: each frame starts when the previous one has
 ended, ms_per_step = a frame's latency) is measured right after the timed region
 and reported as `extra.one_frame_in_flight`.
@@ -38,6 +40,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# HIP maps streams onto 4 hardware queues by default; the frame streams, the default stream and (N > 1) RCCL's streams
+# then share queues, and two frames "in flight" on one hardware queue run one after the other (measured: 1.35 instead of
+# 1.30 ms per frame with four frame streams).  Must be set before the HIP runtime starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 CONFIGS = {
     # name: depth, width, height, spp, use_gi, aperture
@@ -216,15 +222,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inflight", type=int, default=0,
                     help="frames in flight per GPU (renderers / streams used round-robin); 1 = one stream, each frame starts "
-                         "when the previous one has ended; 0 = default: 2, and 4 from four GPUs on")
+                         "when the previous one has ended; 0 = default: 3")
     ap.add_argument("--gather", default="all", choices=["all", "root"],
                     help="N > 1: how the RGBA8 row-block shards meet: 'all' = RCCL all-gather (every rank ends up with the "
                          "frame), 'root' = RCCL gather to rank 0, the presenting rank (north_star / SURVEY 8e: 1/N of the "
                          "bytes on the wire)")
     ap.add_argument("--fused", default="auto", choices=["auto", "0", "1"],
                     help="resolve + pack + reset inside the frame kernel (vrc_render_frame_resolved) instead of a second kernel; "
-                         "auto = on more than four GPUs, where a rank's frame is short enough for the second launch to show "
-                         "(tools/resolve_cost.py: 227 -> 204 us per frame at N = 8, level at N = 4, a loss of 2-3 % at N <= 2)")
+                         "auto = whenever frames overlap (whole-spp work units: the fused path then resolves from registers, "
+                         "never slower, 1 % faster on short shards; tools/shard_inflight.py, tools/resolve_cost.py)")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra measurements (2-bounce extension)")
     ap.add_argument("--tuning", default="", help="blocks_per_cu,refill_threshold,chunk")
     ap.add_argument("--kernel", type=int, default=2,
@@ -299,14 +305,20 @@ def main():
     # one launch (its last work units finish at latency speed with most of the chip idle) overlaps the start of the
     # next frame's launch, like the all-gather of frame i overlaps the render of frame i + 1.  Frames stay independent
     # and complete in order; F = 1 is the plain one-stream loop.
-    F = args.inflight if args.inflight > 0 else (2 if world <= 2 else 4)
-    fused = world > 4 if args.fused == "auto" else args.fused == "1"
+    F = args.inflight if args.inflight > 0 else 3
+    # with frames overlapping, a launch's tail is covered by the next frame's launch: work units of ALL the samples of a tile
+    # (one primary / shadow set-up per tile, no atomics, resolved from registers by the fused path) beat the short units the
+    # library picks for a launch that has the chip to itself (tools/shard_inflight.py)
+    whole_spp_units = F > 1
+    fused = whole_spp_units if args.fused == "auto" else args.fused == "1"
 
-    def make_renderer():
+    def make_renderer(whole=None):
         r = vrc.RayCaster(svo, (W, H))
         r.setLightPosition(light)
         r.use_gi, r.use_samples, r.shadow_samples = bool(cfg["use_gi"]), True, 1
         r.gi_bounces = cfg.get("gi_bounces", 1)
+        if whole_spp_units if whole is None else whole:
+            r.setSampleChunk(spp)
         return r
 
     rcs = [make_renderer() for _ in range(F)]
@@ -351,9 +363,11 @@ def main():
             if dist_on:
                 finish_gather(slot)                            # the frame that used this slot's buffers last
             rc.frame_index = i * spp
-            e0 = torch.cuda.Event(enable_timing=True)
-            e1 = torch.cuda.Event(enable_timing=True)
-            e0.record(ts)
+            use_ev = timed
+            if use_ev:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record(ts)
             if dist_on and fused:
                 rc.renderFrameResolved(cam, spp=spp, dst_ptr=mine[slot].data_ptr(), stream=stream, row_block=ROW_BLOCK, shard_index=rank, shard_count=world)
             elif dist_on:
@@ -362,7 +376,8 @@ def main():
                 rc.renderFrameResolved(cam, spp=spp, stream=stream)
             else:
                 rc.renderFrame(cam, spp=spp, stream=stream)
-            e1.record(ts)
+            if use_ev:
+                e1.record(ts)
             if dist_on:
                 if not fused:                                      # (fused: resolved, packed and reset by the frame kernel)
                     rc.resolveShard(ROW_BLOCK, rank, world, mine[slot].data_ptr(), reset=True, stream=stream)
@@ -381,7 +396,7 @@ def main():
             elif not fused:
                 rc.resolveShard(reset=True, stream=stream)
         state["i"] += 1
-        if timed:
+        if use_ev:
             ev_pairs.append((e0, e1))
 
     def drain():
@@ -419,7 +434,14 @@ def main():
         sum_complexity = sum(x.sum_complexity for x in sts)
         pixels = sum(x.pixels for x in sts)
     st = _Sum
-    kernel_ms = sum(a.elapsed_time(b) for a, b in ev_pairs) / max(1, len(ev_pairs))
+    # events around each launch: with one frame in flight that is the kernel's duration; with F launches sharing the chip
+    # it spans ~F frame periods (and is what rocprofv3 --stats shows as the average duration), so the roofline prices the
+    # kernel on the chip time per launch: first timed launch's start -> last launch's end (over the F streams) / K
+    kernel_ms_bracketed = sum(a.elapsed_time(b) for a, b in ev_pairs) / max(1, len(ev_pairs))
+    if F > 1 and ev_pairs:
+        kernel_ms = max(ev_pairs[0][0].elapsed_time(b) for _, b in ev_pairs[-F:]) / len(ev_pairs)
+    else:
+        kernel_ms = kernel_ms_bracketed
 
     rays, steps_sum, pixels = st.rays, st.sum_complexity, st.pixels
     if dist_on:
@@ -485,7 +507,7 @@ def main():
     extras = {}
     if rank == 0 and world == 1 and not dist_on and not args.no_extras and F > 1:
         # the same frames one at a time on one stream: a frame's latency, and the kernel's duration when it has the chip alone
-        rc1 = make_renderer()
+        rc1 = make_renderer(whole=False)                        # the library's own unit policy for a launch alone on the chip
         ts = tstreams[0]
         n1 = max(10, min(args.steps, 50))
         evs = []
@@ -508,32 +530,42 @@ def main():
         extras["one_frame_in_flight"] = {
             "ms_per_step": round(dt1 / n1 * 1e3, 4), "kernel_ms": round(sum(a.elapsed_time(b) for a, b in evs) / len(evs), 4),
             "value": round(st1.rays / (3 + n1) * n1 / dt1 / 1e6, 2), "unit": "Mrays/s", "steps": n1,
-            "note": "--inflight 1: one stream, each frame starts when the previous one has ended"}
+            "note": "--inflight 1: one stream, each frame starts when the previous one has ended; the library's automatic work-unit "
+                    "policy, resolve as a second kernel"}
     if rank == 0 and world == 1 and not dist_on and not args.no_extras and args.config == "c3":
-        rc2 = make_renderer()
-        rc2.gi_bounces = 2
-        ts = tstreams[0]
+        # the same way as the timed region: F renderers / streams round-robin, same unit policy, same resolve
+        rcs2 = [make_renderer() for _ in range(F)]
+        for r2 in rcs2:
+            r2.gi_bounces = 2
         n2 = max(10, min(args.steps, 50))
-        with torch.cuda.stream(ts):
-            for i in range(3):
-                rc2.frame_index = i * spp
-                rc2.renderFrame(cam, spp=spp, stream=ts.cuda_stream)
-                rc2.resolveShard(reset=True, stream=ts.cuda_stream)
-            torch.cuda.synchronize()
-            rc2.stats(reset=True, stream=ts.cuda_stream)
-            t2 = time.perf_counter()
-            for i in range(n2):
-                rc2.frame_index = i * spp
-                rc2.renderFrame(cam, spp=spp, stream=ts.cuda_stream)
-                rc2.resolveShard(reset=True, stream=ts.cuda_stream)
-            torch.cuda.synchronize()
-            dt2 = time.perf_counter() - t2
-        st2 = rc2.stats(stream=ts.cuda_stream)
+
+        def frames2(i0, n):
+            for i in range(i0, i0 + n):
+                r2, ts2 = rcs2[i % F], tstreams[i % F]
+                r2.frame_index = i * spp
+                if fused:
+                    r2.renderFrameResolved(cam, spp=spp, stream=ts2.cuda_stream)
+                else:
+                    r2.renderFrame(cam, spp=spp, stream=ts2.cuda_stream)
+                    r2.resolveShard(reset=True, stream=ts2.cuda_stream)
+        frames2(0, 2 * F)
+        torch.cuda.synchronize()
+        for r2 in rcs2:
+            r2.stats(reset=True, stream=tstreams[0].cuda_stream)
+        t2 = time.perf_counter()
+        frames2(2 * F, n2)
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t2
+
+        class st2:
+            rays = sum(r2.stats(stream=tstreams[0].cuda_stream).rays for r2 in rcs2)
+            sum_complexity = sum(r2.stats(stream=tstreams[0].cuda_stream).sum_complexity for r2 in rcs2)
         extras["gi_2_bounce_extension"] = {
             "value": round(st2.rays / dt2 / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(dt2 / n2 * 1e3, 4), "steps": n2,
             "rays_per_frame": st2.rays // n2, "loop_iterations_per_frame": st2.sum_complexity // n2,
             "note": "extension without reference behaviour: bounce 2 = getGlobalIllumination applied again at the GI hit "
-                    "(oracle/vrc_oracle.c global_illumination, level 1); same frame, same kernel, measured right after the timed region"}
+                    "(oracle/vrc_oracle.c global_illumination, level 1); same frame, same frames in flight and unit policy as the timed "
+                    "region, measured right after it"}
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -548,12 +580,19 @@ def main():
         # passes recorded in profiles/traffic.json -- only when that record was taken on THIS tree's kernel sources
         # (the stage-synchronous kernel has a specialisation for the pinhole camera, see csrc/vrc_kernels.hip launch_render)
         pinhole = cam.aperture == 0.0 and math.copysign(1.0, cam.aperture) > 0 and 1e-30 <= cam.focal_length < float("inf")
-        sync_kernel_name = ("k_render_sync_pinhole" if pinhole else "k_render_sync") + ("" if cfg.get("gi_bounces", 1) <= 1 else "2")
-        rec, why = pmc_record(f"{args.config}_n{world}") if args.kernel == 2 else (None, "PMC record exists for k_render_sync only")
+        sync_kernel_name = (("k_render_sync_pinhole" if pinhole else "k_render_sync") + ("" if cfg.get("gi_bounces", 1) <= 1 else "2")
+                            + ("_resolved" if fused else ""))
+        rec, why = pmc_record(f"{args.config}_n{world}" + ("" if F > 1 else "_inflight1")) if args.kernel == 2 else (None, "PMC record exists for k_render_sync only")
         traffic = rec["traffic_bytes"] if rec else None
         roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
                 "kernel": sync_kernel_name if args.kernel == 2 else {0: "k_render_tile", 1: "k_render"}[args.kernel], "kernel_ms": round(kernel_ms, 4),
+                "kernel_ms_is": ("events around each launch, averaged (launches do not overlap)" if F == 1 else
+                                 f"chip time per launch: HIP events from the first timed launch's start to the last one's end on the {F} "
+                                 "launch streams / steps" + (" (includes this rank's resolve / exchange kernels)" if dist_on else "")
+                                 + "; kernel_ms_bracketed = events around one launch, which overlaps its neighbours "
+                                 "(= the average duration rocprofv3 --stats reports for this command)"),
+                "kernel_ms_bracketed": round(kernel_ms_bracketed, 4),
                 "kernel_ms_max_rank": round(kernel_ms_max, 4), "algorithmic_bytes_per_launch": int(alg_bytes),
                 "achieved_is": "ALGORITHMIC bytes (SURVEY 8d: 8 B per walk-loop iteration + 32 B per pixel) / kernel time -- nominal by "
                                "construction: the tree is L1/L2-resident, see traffic_frac_of_peak, and the binding limit is VALU "
@@ -583,7 +622,7 @@ def main():
                        "loop_iterations_per_frame": steps_sum // args.steps,
                        "camera_pitch": args.pitch, "lsvo_nodes": svo.n_nodes,
                        "lsvo_gpu_build_ms": round(svo.build_ms, 3), "lsvo_gpu_build_call_ms": round(build_call_ms, 3),
-                       "frames_in_flight": F, "resolve_fused_into_frame_kernel": fused, "host_enqueue_us_per_step": round(host_enqueue_us, 1), "sharding": f"{ROW_BLOCK}-row blocks round-robin over {world} GPU(s)"
+                       "frames_in_flight": F, "whole_spp_work_units": whole_spp_units, "resolve_fused_into_frame_kernel": fused, "host_enqueue_us_per_step": round(host_enqueue_us, 1), "sharding": f"{ROW_BLOCK}-row blocks round-robin over {world} GPU(s)"
                        + (f", RCCL {'gather to rank 0' if args.gather == 'root' else 'all-gather'} of RGBA8 shards" if dist_on else ""),
                        "ranks_in_process_group": (dist.get_world_size() if dist_on else 1),
                        "gathered_frame_equals_unsharded": verified},
