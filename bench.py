@@ -603,8 +603,11 @@ def main():
             roof["issue"] = {"valu_wave_instr_per_launch": rec.get("valu_wave_instr"),
                              "lane_utilisation": rec.get("lane_utilisation"),
                              "simd_cycles_per_valu_instr": rec.get("simd_cycles_per_valu_instr"),
-                             "note": "rocprofv3 PMC, per launch: SQ_INSTS_VALU; SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); "
-                                     "GRBM_GUI_ACTIVE / 8 x 1024 SIMDs / SQ_INSTS_VALU"}
+                             "simd_cycles_per_valu_instr_timed": (round(kernel_ms * 1e-3 * 2.4e9 * 1024.0 / rec["valu_wave_instr"], 3)
+                                                                  if rec.get("valu_wave_instr") else None),
+                             "note": "rocprofv3 PMC, per launch (the profiler runs the launches one at a time): SQ_INSTS_VALU; "
+                                     "SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); GRBM_GUI_ACTIVE / 8 x 1024 SIMDs / SQ_INSTS_VALU; "
+                                     "..._timed = this run's kernel_ms x 2.4 GHz x 1024 SIMDs / SQ_INSTS_VALU (launches overlapping as timed)"}
         else:
             roof["traffic_note"] = why
         out = {

@@ -19,5 +19,8 @@ for name in sorted(rows):
     per = defaultdict(float)
     for d, v in rows[name]:
         per[d] += v
-    vals = list(per.values())
-    print(f"{name:36s} launches {len(vals):3d}  mean {sum(vals) / len(vals):18.1f}  min {min(vals):18.1f}  max {max(vals):18.1f}")
+    vals = sorted(per.values())
+    # the median is what tools/update_traffic.py records: with frames in flight a profiled launch now and then carries a
+    # neighbour's counts as well (twice the waves), which the mean would keep
+    median = vals[len(vals) // 2] if len(vals) % 2 else 0.5 * (vals[len(vals) // 2 - 1] + vals[len(vals) // 2])
+    print(f"{name:36s} launches {len(vals):3d}  mean {sum(vals) / len(vals):18.1f}  min {min(vals):18.1f}  max {max(vals):18.1f}  median {median:18.1f}")

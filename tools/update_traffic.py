@@ -25,7 +25,7 @@ def main():
     for line in open(os.path.join(src, "summary.txt")):
         f = line.split()
         if len(f) >= 5 and f[1] == "launches":
-            vals[f[0]] = float(f[4])
+            vals[f[0]] = float(f[10]) if len(f) >= 11 and f[9] == "median" else float(f[4])
     source_hash = open(os.path.join(src, "source_hash.txt")).read().strip()
     import bench
     commit = None
