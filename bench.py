@@ -567,6 +567,41 @@ def main():
                     "(oracle/vrc_oracle.c global_illumination, level 1); same frame, same frames in flight and unit policy as the timed "
                     "region, measured right after it"}
 
+    if rank == 0 and world == 1 and not dist_on and not args.no_extras and cfg["aperture"] == 0.0 and args.kernel == 2:
+        # untimed extra, beyond the reference: the same frames with vrc_renderer_set_invariant_ray_reuse -- a pinhole camera's
+        # primary ray and the shadow ray of its hit are the same for every sample, the reference (and `value`) walk them
+        # once per sample, here once per pixel and frame.  Same image bit for bit (tests/test_gpu_reuse.py); its Mrays/s
+        # counts the walks EXECUTED, so ms_per_step is the figure to compare
+        rcs3 = [make_renderer() for _ in range(F)]
+        for r3 in rcs3:
+            r3.setInvariantRayReuse(True)
+        n3 = max(10, min(args.steps, 50))
+
+        def frames3(i0, n):
+            for i in range(i0, i0 + n):
+                r3, ts3 = rcs3[i % F], tstreams[i % F]
+                r3.frame_index = i * spp
+                if fused:
+                    r3.renderFrameResolved(cam, spp=spp, stream=ts3.cuda_stream)
+                else:
+                    r3.renderFrame(cam, spp=spp, stream=ts3.cuda_stream)
+                    r3.resolveShard(reset=True, stream=ts3.cuda_stream)
+        frames3(0, 2 * F)
+        torch.cuda.synchronize()
+        for r3 in rcs3:
+            r3.stats(reset=True, stream=tstreams[0].cuda_stream)
+        t3 = time.perf_counter()
+        frames3(2 * F, n3)
+        torch.cuda.synchronize()
+        dt3 = time.perf_counter() - t3
+        rays3 = sum(r3.stats(stream=tstreams[0].cuda_stream).rays for r3 in rcs3)
+        extras["invariant_rays_walked_once"] = {
+            "ms_per_step": round(dt3 / n3 * 1e3, 4), "value": round(rays3 / dt3 / 1e6, 2), "unit": "Mrays/s (walks executed)", "steps": n3,
+            "rays_per_frame_executed": rays3 // n3, "rays_per_frame_reference": rays // args.steps,
+            "note": "beyond the reference, off by default: pinhole camera, the sample-invariant primary and shadow walks done once per "
+                    "pixel and frame instead of once per sample; same image bit for bit; same frames in flight and unit policy as the "
+                    "timed region (whole-spp units make the reuse span the frame's samples), measured right after it"}
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         # roofline of the dominant kernel (k_render_sync*), this rank's launches:

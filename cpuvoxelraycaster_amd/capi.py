@@ -102,6 +102,7 @@ SYMBOLS = {
     "vrc_renderer_set_tuning": (_int, [_vp, _u32, _u32, _u32]),
     "vrc_renderer_set_kernel": (_int, [_vp, _u32]),
     "vrc_renderer_set_sample_chunk": (_int, [_vp, _u32]),
+    "vrc_renderer_set_invariant_ray_reuse": (_int, [_vp, _u32]),
 }
 
 _lib = None

@@ -49,6 +49,7 @@ struct Tuning {
     bool blocks_per_cu_set = false;
     uint32_t sample_chunk = 0;   // 0 = automatic
     uint32_t tail_units_per_wave = 3;   // automatic chunking: units of half the chunk for the last tiles (0 = off)
+    bool reuse_invariant = false;       // pinhole camera: walk a unit's sample-invariant rays once (never a process default)
 };
 Tuning g_tuning;
 std::mutex g_tuning_mu;
@@ -153,6 +154,13 @@ extern "C" int vrc_renderer_set_sample_chunk(vrc_renderer* r, uint32_t samples_p
 {
     if (!r) return fail(VRC_ERR_INVALID, "null renderer");
     return apply_sample_chunk(r->tuning, samples_per_unit);
+}
+extern "C" int vrc_renderer_set_invariant_ray_reuse(vrc_renderer* r, uint32_t on)
+{
+    if (!r) return fail(VRC_ERR_INVALID, "null renderer");
+    if (on > 1) return fail(VRC_ERR_INVALID, "vrc_renderer_set_invariant_ray_reuse: on = %u (0 or 1)", on);
+    r->tuning.reuse_invariant = on != 0;
+    return VRC_OK;
 }
 extern "C" int vrc_renderer_set_kernel(vrc_renderer* r, uint32_t kernel)
 {
@@ -557,6 +565,7 @@ int render_impl(vrc_renderer* r, const vrc_camera* cam, const vrc_frame_params* 
         }
     }
     a.fused_resolve = fused ? 1u : 0u;
+    a.reuse_invariant = tuning.reuse_invariant ? 1u : 0u;
     a.tile_done = r->d_tile_done;
     a.resolve_dst = (uint32_t*)dst;
     uint64_t want = (items + VRC_RENDER_BLOCK - 1) / VRC_RENDER_BLOCK;

@@ -66,6 +66,9 @@ struct FrameArgs {
     // sums into RGBA8 -- image, and resolve_dst (packed shard rows, may be NULL) -- and leaves the accumulators at zero:
     // samples_to_image + pack_shard + reset_samples without a second kernel.  tile_done: one arrival counter per tile.
     uint32_t fused_resolve;
+    // pinhole kernels (vrc_renderer_set_invariant_ray_reuse): walk a work unit's sample-invariant rays (the primary ray
+    // and the shadow ray of its hit) once instead of once per sample; same image, fewer walks executed and counted
+    uint32_t reuse_invariant;
     uint32_t* tile_done;
     uint32_t* resolve_dst;
     vrc_camera cam;

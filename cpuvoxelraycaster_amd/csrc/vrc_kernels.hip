@@ -1052,6 +1052,11 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
         if constexpr (PINHOLE) {
             // ---- the stages that do not depend on the sample: set up once, walked once per sample of the unit
             const uint32_t n_samples = s_end - s_begin;
+            // the reference walks the identical primary and shadow ray again for every sample, and so does this kernel
+            // unless the caller allowed reuse: then one walk serves all the samples of the unit (same hit, same image;
+            // the counters then count the walks executed, not the reference's)
+            const bool reuse = ka->reuse_invariant != 0u;
+            const uint32_t n_walks = reuse ? 1u : n_samples, n_shadow_walks = reuse ? 1u : n_samples * shadow_samples;
             bool hit = false;
             uint32_t albedo = 0u;
             float light_intensity = 0.0f;
@@ -1075,7 +1080,7 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
                 Ray r0, r;
                 bool active = ray_setup(r0, root, ox, oy, oz, dx, dy, dz);
                 r = r0;
-                for (uint32_t k = 0; k < n_samples; ++k) {                          // raycaster.hpp:131, once per sample
+                for (uint32_t k = 0; k < n_walks; ++k) {                            // raycaster.hpp:131, once per sample
                     r = r0;
                     ray_run<VRC_RENDER_BLOCK, 0>(r, active, nodes, stk, depth, 0.0f, 0.0f);
                     n_rays += 1u; n_steps += r.complexity;
@@ -1103,7 +1108,7 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
                     normalize3(dx, dy, dz);
                     const float lit = smax(0.0f, dot3(dx, dy, dz, h.nx, h.ny, h.nz));           // :156
                     active = ray_setup(r0, root, ox, oy, oz, dx, dy, dz);
-                    for (uint32_t k = n_samples * shadow_samples; k--;) {
+                    for (uint32_t k = n_shadow_walks; k--;) {
                         r = r0;
                         ray_run<VRC_RENDER_BLOCK, 0>(r, active, nodes, stk, depth, 0.0f, 0.0f);
                         n_rays += 1u; n_steps += r.complexity;

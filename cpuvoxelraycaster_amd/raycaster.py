@@ -208,6 +208,11 @@ class RayCaster:
     def setSampleChunk(self, samples_per_unit):
         check(capi.load().vrc_renderer_set_sample_chunk(self._h, samples_per_unit))
 
+    def setInvariantRayReuse(self, on=True):
+        """beyond the reference: pinhole camera, walk a work unit's primary and shadow ray once instead of once per sample
+        (same image; stats then count the walks executed).  include/vrc.h: vrc_renderer_set_invariant_ray_reuse."""
+        check(capi.load().vrc_renderer_set_invariant_ray_reuse(self._h, 1 if on else 0))
+
     def renderFrameResolved(self, camera, spp=1, dst_ptr=None, stream=None, row_block=0, shard_index=0, shard_count=1):
         """renderFrame + resolveShard(..., reset=True) in one launch (vrc_render_frame_resolved): the frame's samples
         rendered, resolved into the image (and the packed shard buffer dst_ptr), accumulators left at zero."""

@@ -303,6 +303,15 @@ int vrc_set_sample_chunk(uint32_t samples_per_unit);
 int vrc_renderer_set_tuning(vrc_renderer *r, uint32_t blocks_per_cu, uint32_t refill_threshold, uint32_t chunk);
 int vrc_renderer_set_kernel(vrc_renderer *r, uint32_t kernel);
 int vrc_renderer_set_sample_chunk(vrc_renderer *r, uint32_t samples_per_unit);
+/* Beyond the reference (off by default).  With aperture exactly +0 -- the reference's default
+ * camera -- a pixel's primary ray and the shadow ray(s) of its hit are the same for every
+ * sample, and RayCaster::renderRay (raycaster.hpp:119-167) walks them again each time.  on = 1
+ * lets the stage-synchronous kernel walk them ONCE per work unit (tile x sample chunk: once per
+ * pixel and frame with vrc_renderer_set_sample_chunk(r, spp)) and share the result between the
+ * unit's samples; the GI rays stay per sample.  Image, accumulators and primary capture are bit
+ * for bit the same; vrc_frame_stats.rays / sum_complexity then count the walks EXECUTED, i.e.
+ * fewer than the reference's.  No effect with aperture != 0 or on the A/B kernels 0 and 1. */
+int vrc_renderer_set_invariant_ray_reuse(vrc_renderer *r, uint32_t on);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,103 @@
+"""vrc_renderer_set_invariant_ray_reuse (beyond the reference, off by default): with a pinhole camera the primary ray and
+the shadow ray(s) of its hit are the same for every sample; walked once per work unit instead of once per sample the frame
+is still the oracle's bit for bit -- image, accumulators, primary capture -- and the counters count exactly the walks that
+were left out; with a lens (aperture != 0) or on the A/B kernels the knob changes nothing."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def scene(built, heights, textures):
+    import cpuvoxelraycaster_amd as vrc
+    nodes = vrc.build_terrain_lsvo(heights, 7)
+    return nodes, vrc.LSVO(nodes, 7, textures=textures)
+
+
+def make(vrc, svo, W, H, chunk=None, reuse=False, kernel=None, shadow_samples=1):
+    rc = vrc.RayCaster(svo, (W, H))
+    rc.setLightPosition(vrc.reference_light(7))
+    rc.use_gi = rc.use_samples = True
+    rc.shadow_samples = shadow_samples
+    if chunk is not None:
+        rc.setSampleChunk(chunk)
+    if kernel is not None:
+        rc.setKernel(kernel)
+    rc.setInvariantRayReuse(reuse)
+    return rc
+
+
+@pytest.mark.parametrize("shadow_samples", [1, 3])
+@pytest.mark.parametrize("chunk", [0, 1, 2, 6])
+@pytest.mark.parametrize("size", [(200, 100), (161, 93)])
+def test_reuse_same_frame_fewer_walks(scene, size, chunk, shadow_samples):
+    import cpuvoxelraycaster_amd as vrc
+    nodes, svo = scene
+    W, H = size
+    spp = 6
+    cam = vrc.reference_camera(7, pitch=-0.5)
+    a = make(vrc, svo, W, H, chunk, False, shadow_samples=shadow_samples)
+    b = make(vrc, svo, W, H, chunk, True, shadow_samples=shadow_samples)
+    for frame in range(2):
+        a.renderFrame(cam, spp=spp)
+        b.renderFrame(cam, spp=spp)
+        assert np.array_equal(a.readAccum(), b.readAccum()), (size, chunk, frame)
+    a.samples_to_image(); b.samples_to_image()
+    assert np.array_equal(a.readImage(), b.readImage())
+    sa, sb = a.stats(), b.stats()
+    assert (sa.pixels, sa.primary_hits) == (sb.pixels, sb.primary_hits)
+    assert sb.rays <= sa.rays and sb.sum_complexity <= sa.sum_complexity
+    if chunk:
+        # a unit of c samples walks 1 instead of c primary rays per pixel and 1 instead of c x shadow_samples shadow rays
+        # per primary hit (pixels / hits per sample, summed over the two frames)
+        pixels, hits, units = sa.pixels // spp, sa.primary_hits // spp, spp // chunk
+        assert sa.rays - sb.rays == units * ((chunk - 1) * pixels + (chunk * shadow_samples - 1) * hits)
+
+
+def test_reuse_fused_whole_spp_equals_oracle(scene, textures):
+    """the form bench.py's extra uses: whole-spp units, fused resolve, reuse on -- against the oracle's frame"""
+    import cpuvoxelraycaster_amd as vrc
+    nodes, svo = scene
+    top, side = textures
+    W, H, spp = 160, 90, 4
+    cam = vrc.reference_camera(7, pitch=-0.5)
+    rc = make(vrc, svo, W, H, chunk=spp, reuse=True)
+    light = vrc.reference_light(7)
+    ocam = O.make_camera(tuple(cam.position), tuple(cam.rot), cam.fov, cam.aperture, cam.focal_length)
+    rays = 0
+    for frame in range(2):
+        rc.renderFrameResolved(cam, spp=spp)
+        acc = None
+        for s in range(spp):
+            p = O.make_params(W, H, light, use_gi=1, use_samples=1, shadow_samples=1, frame_index=frame * spp + s)
+            _, acc, _, st = O.render_frame(nodes, 7, top, side, ocam, p, accum=acc, threads=8)
+            rays += st.rays
+        assert np.array_equal(rc.readImage(), O.samples_to_image(acc)), frame
+    st = rc.stats()
+    assert st.rays == rays - (spp - 1) * (st.pixels // spp + st.primary_hits // spp)
+
+
+def test_reuse_is_inert_with_a_lens_and_on_the_other_kernels(scene):
+    import cpuvoxelraycaster_amd as vrc
+    nodes, svo = scene
+    W, H, spp = 120, 72, 3
+    dof = vrc.reference_camera(7, pitch=-0.5, aperture=0.6, focal_length=30.0)
+    pin = vrc.reference_camera(7, pitch=-0.5)
+    for cam, kernel in ((dof, None), (pin, 0), (pin, 1)):
+        a, b = make(vrc, svo, W, H, None, False, kernel), make(vrc, svo, W, H, None, True, kernel)
+        a.renderFrame(cam, spp=spp); b.renderFrame(cam, spp=spp)
+        assert np.array_equal(a.readAccum(), b.readAccum())
+        sa, sb = a.stats(), b.stats()
+        assert (sa.rays, sa.sum_complexity) == (sb.rays, sb.sum_complexity)
+
+
+def test_reuse_argument_checked(scene):
+    import cpuvoxelraycaster_amd as vrc
+    nodes, svo = scene
+    rc = make(vrc, svo, 16, 16)
+    L = vrc.capi.load()
+    assert L.vrc_renderer_set_invariant_ray_reuse(rc._h, 2) == -1
+    assert L.vrc_renderer_set_invariant_ray_reuse(None, 1) == -1
