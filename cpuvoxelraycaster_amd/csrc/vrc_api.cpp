@@ -135,6 +135,30 @@ int vrc::require_device(int device, int* cu_count)
 
 using vrc::require_device;
 
+extern "C" int vrc_stream_create(int device, void** stream)
+{
+    if (!stream) return fail(VRC_ERR_INVALID, "vrc_stream_create: null argument");
+    *stream = nullptr;
+    if (int rc = require_device(device, nullptr)) return rc;
+    hipStream_t st = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    *stream = st;
+    return VRC_OK;
+}
+extern "C" int vrc_stream_destroy(int device, void* stream)
+{
+    if (!stream) return VRC_OK;
+    if (int rc = require_device(device, nullptr)) return rc;
+    HIP_TRY(hipStreamDestroy((hipStream_t)stream));
+    return VRC_OK;
+}
+extern "C" int vrc_stream_synchronize(int device, void* stream)
+{
+    if (int rc = require_device(device, nullptr)) return rc;
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return VRC_OK;
+}
+
 extern "C" int vrc_set_sample_chunk(uint32_t samples_per_unit)
 {
     std::lock_guard<std::mutex> lk(g_tuning_mu);

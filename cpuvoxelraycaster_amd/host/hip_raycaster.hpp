@@ -17,6 +17,7 @@
 #include <cstdint>
 #include <fstream>
 #include <list>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -252,6 +253,21 @@ public:
     }
 
     vrc_renderer* handle() const { return r_; }
+    // sample counter of the next frame (the RNG key: frame_index + sample); renderFrame* advance it by spp
+    void setFrameIndex(uint32_t frame_index) { frame_index_ = frame_index; }
+    uint32_t frameIndex() const { return frame_index_; }
+    std::vector<uint8_t> render_image(void* stream) const     // the same copy, ordered after (and waiting for) `stream` only
+    {
+        std::vector<uint8_t> img((size_t)width_ * height_ * 4);
+        check(vrc_read_image(r_, img.data(), stream), "vrc_read_image");
+        return img;
+    }
+    vrc_frame_stats stats(bool reset, void* stream)
+    {
+        vrc_frame_stats s;
+        check(vrc_get_stats(r_, &s, reset ? 1 : 0, stream), "vrc_get_stats");
+        return s;
+    }
 
     bool use_gi = false;        // raycaster.hpp:274
     bool use_samples = false;   // raycaster.hpp:275
@@ -263,6 +279,70 @@ private:
     uint32_t frame_index_ = 0;
     uint32_t row_block_ = 0, shard_index_ = 0, shard_count_ = 1;
     Vec3 light_{0, 0, 0};
+};
+
+// Progressive frames kept in flight -- for hosts that do not need frame i before they issue
+// frame i + 1: an offline render, a replay (ReplayElements below), a multi-GPU shard.  `frames_in_flight` renderers and
+// streams take turns; a work unit is a tile's whole sample set and the resolve is fused into the frame kernel, which is the
+// fastest form once launches overlap.  submit() returns at once; image(slot) waits for that slot's frame only.  Frame n
+// is the frame a single HipRayCaster would render n-th with the same spp (frame_index = n * spp), bit for bit.
+class HipFramePipeline {
+public:
+    HipFramePipeline(const HipLSVO& svo, uint32_t width, uint32_t height, uint32_t spp, uint32_t frames_in_flight = 3, int device = 0)
+        : device_(device), spp_(spp ? spp : 1)
+    {
+        if (frames_in_flight == 0) frames_in_flight = 1;
+        for (uint32_t i = 0; i < frames_in_flight; ++i) {
+            slots_.emplace_back(new HipRayCaster(svo, width, height));
+            slots_.back()->setSampleChunk(spp_);
+            void* st = nullptr;
+            check(vrc_stream_create(device, &st), "vrc_stream_create");
+            streams_.push_back(st);
+        }
+    }
+    ~HipFramePipeline()
+    {
+        for (void* st : streams_) { vrc_stream_synchronize(device_, st); vrc_stream_destroy(device_, st); }
+    }
+    HipFramePipeline(const HipFramePipeline&) = delete;
+    HipFramePipeline& operator=(const HipFramePipeline&) = delete;
+
+    void setLightPosition(const Vec3& position) { for (auto& r : slots_) r->setLightPosition(position); }
+    void setUseGI(bool on) { for (auto& r : slots_) r->use_gi = on; }
+    void setSeed(uint32_t seed) { for (auto& r : slots_) r->seed = seed; }
+    void setInvariantRayReuse(bool on) { for (auto& r : slots_) r->setInvariantRayReuse(on); }
+    void setShard(uint32_t row_block, uint32_t shard_index, uint32_t shard_count)
+    {
+        for (auto& r : slots_) r->setShard(row_block, shard_index, shard_count);
+    }
+    uint32_t framesInFlight() const { return (uint32_t)slots_.size(); }
+
+    // Issues frame number `submitted()` and returns its slot.  The slot's previous frame (F submits ago) is overwritten:
+    // read it first.  `shard_dev`: where the resolved rows also go (device; multi-GPU exchange buffer), may be null.
+    uint32_t submit(const CameraState& camera, void* shard_dev = nullptr)
+    {
+        const uint32_t slot = (uint32_t)(n_ % slots_.size());
+        slots_[slot]->setFrameIndex((uint32_t)(n_ * spp_));
+        slots_[slot]->renderFrameResolved(camera, spp_, shard_dev, streams_[slot]);
+        ++n_;
+        return slot;
+    }
+    uint64_t submitted() const { return n_; }
+    void wait(uint32_t slot) { check(vrc_stream_synchronize(device_, streams_[slot]), "vrc_stream_synchronize"); }
+    void waitAll() { for (uint32_t i = 0; i < slots_.size(); ++i) wait(i); }
+    std::vector<uint8_t> image(uint32_t slot) { return slots_[slot]->render_image(streams_[slot]); }   // waits for that slot
+    void* image_device_ptr(uint32_t slot) const { return vrc_image_device_ptr(slots_[slot]->handle()); }
+    void* stream(uint32_t slot) const { return streams_[slot]; }
+    HipRayCaster& raycaster(uint32_t slot) { return *slots_[slot]; }
+    // counters of the frames rendered on `slot` since the last reset (waits for that slot)
+    vrc_frame_stats stats(uint32_t slot, bool reset = false) { return slots_[slot]->stats(reset, streams_[slot]); }
+
+private:
+    int device_;
+    uint32_t spp_;
+    uint64_t n_ = 0;
+    std::vector<std::unique_ptr<HipRayCaster>> slots_;
+    std::vector<void*> streams_;
 };
 
 // The blend / upscale chain main.cpp runs on render_image after every frame (main.cpp:160-182: render_tex,

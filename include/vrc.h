@@ -184,6 +184,13 @@ typedef struct vrc_frame_stats {
     uint64_t pixels;          /* pixel-samples shaded */
 } vrc_frame_stats;
 
+/* Streams for hosts that do not link the HIP runtime themselves: every `void *stream` argument of
+ * this header is a hipStream_t (NULL = the default stream).  A host that keeps frames in flight
+ *  needs one stream per frame in flight. */
+int vrc_stream_create(int device, void **stream);
+int vrc_stream_destroy(int device, void *stream);
+int vrc_stream_synchronize(int device, void *stream);   /* blocks the calling thread until the stream's work is done */
+
 /* RayCaster(svo, render_size) (raycaster.hpp:48-60): framebuffer cleared to
  * opaque black (sf::Image::create), accumulators zero.  The scene must outlive
  * every vrc_render_frame call on the renderer (as `const LSVO<9>& svo` must

@@ -65,3 +65,36 @@ def test_replay_file_through_cpp_adapter_matches_oracle(built, heights, textures
         assert int(fr[2], 16) == fnv1a(img.tobytes()), f"tick {i}"
         hit_frames += int(fr[5]) > W * H // 4
     assert hit_frames >= len(ticks) // 2        # the orbit looks at the terrain
+
+
+def test_replay_through_frame_pipeline_equals_tick_by_tick(built, heights, textures, tmp_path):
+    """vrc_host::HipFramePipeline (frames in flight: one renderer + stream per slot, whole-spp units, fused resolve) renders the
+    replay frame for frame like the tick-by-tick loop -- same image hash and counters per frame, for 1, 2, 3 and 5 frames in
+    flight --, and with the invariant-ray reuse the same images from fewer walks."""
+    import cpuvoxelraycaster_amd as vrc
+    depth, W, H, spp = 9, 161, 93, 3
+    nodes = vrc.build_terrain_lsvo(heights, depth)
+    top, side = textures
+    nodes.tofile(tmp_path / "nodes.bin")
+    top.tofile(tmp_path / "top.rgb")
+    side.tofile(tmp_path / "side.rgb")
+    ticks = [ln.split() for ln in open(REPLAY).read().splitlines() if ln.strip()]
+    exe = str(tmp_path / "replay_main")
+    libdir = os.path.join(ROOT, "cpuvoxelraycaster_amd")
+    subprocess.check_call(["g++", "-std=c++14", "-O1", os.path.join(ROOT, "tests", "cpp", "replay_main.cpp"),
+                           "-o", exe, "-L" + libdir, "-l:libvrc_hip.so", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    base = [exe, str(tmp_path / "nodes.bin"), str(depth), str(tmp_path / "top.rgb"), str(tmp_path / "side.rgb"),
+            str(W), str(H), str(spp), REPLAY]
+
+    def frames(extra):
+        out = subprocess.run(base + extra, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stdout + out.stderr
+        return re.findall(r"frame (\d+) t=(\S+) fnv=([0-9a-f]+) rays=(\d+) steps=(\d+) hits=(\d+)", out.stdout)
+
+    want = frames([])
+    assert len(want) == len(ticks) and len({f[2] for f in want}) > len(ticks) // 2      # the orbit moves
+    for F in (1, 2, 3, 5):
+        assert frames([str(F)]) == want, F
+    reuse = frames(["3", "reuse"])
+    assert [f[:3] for f in reuse] == [f[:3] for f in want] and [f[5] for f in reuse] == [f[5] for f in want]
+    assert all(int(a[3]) < int(b[3]) and int(a[4]) < int(b[4]) for a, b in zip(reuse, want) if int(b[5]))

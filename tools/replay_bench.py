@@ -11,6 +11,8 @@ import sys
 
 import numpy as np
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # more than three frame streams would otherwise share hardware queues
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
@@ -83,6 +85,9 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=4)
+    ap.add_argument("--inflight", type=int, default=0, help="F > 0: F renderers / streams take turns (whole-spp work units, fused "
+                    "resolve), the orbit is rendered 5 times over and the figure is wall time per frame")
+    ap.add_argument("--reuse", action="store_true", help="with --inflight: vrc_renderer_set_invariant_ray_reuse")
     args = ap.parse_args()
     import torch
     import cpuvoxelraycaster_amd as vrc
@@ -93,6 +98,38 @@ def main():
     ticks = load_replay(path)
     depth = 9
     svo = vrc.LSVO.fromFastNoiseTerrain(depth, textures=vrc.load_textures())
+    if args.inflight:
+        import time
+        F = args.inflight
+        rcs, streams = [], [torch.cuda.Stream() for _ in range(F)]
+        for _ in range(F):
+            r = vrc.RayCaster(svo, (args.width, args.height))
+            r.setLightPosition(vrc.reference_light(depth))
+            r.use_gi, r.use_samples, r.shadow_samples = True, True, 1
+            r.setSampleChunk(args.spp)
+            r.setInvariantRayReuse(args.reuse)
+            rcs.append(r)
+        cams = [vrc.make_camera((x, y, z), vrc.make_rotation(vx, vy)) for (t, x, y, z, vx, vy) in ticks]
+
+        def orbit(i0):
+            for k, cam in enumerate(cams):
+                i = i0 + k
+                rcs[i % F].frame_index = i * args.spp
+                rcs[i % F].renderFrameResolved(cam, spp=args.spp, stream=streams[i % F].cuda_stream)
+        orbit(0)
+        torch.cuda.synchronize()
+        for r in rcs:
+            r.stats(reset=True)
+        t0 = time.perf_counter()
+        for rep in range(5):
+            orbit((rep + 1) * len(cams))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        rays = sum(r.stats().rays for r in rcs)
+        print(json.dumps({"replay": path, "ticks": len(ticks), "frames_in_flight": F, "invariant_ray_reuse": args.reuse,
+                          "ms_per_frame": round(dt / (5 * len(cams)) * 1e3, 4), "Mrays_per_s": round(rays / dt / 1e6, 1),
+                          "rays_per_frame": rays // (5 * len(cams))}))
+        return
     rc = vrc.RayCaster(svo, (args.width, args.height))
     rc.setLightPosition(vrc.reference_light(depth))
     rc.use_gi, rc.use_samples, rc.shadow_samples = True, True, 1
