@@ -70,12 +70,15 @@ KERNEL_SOURCES = ["vrc_kernels.hip", "vrc_walk.h", "vrc_device.h", "vrc_internal
 
 
 def kernel_source_hash():
-    """Identifies the frame-kernel sources a PMC measurement belongs to (profiles/traffic.json is stamped with it)."""
+    """Identifies the frame-kernel sources AND the compiler flags a PMC measurement belongs to (profiles/traffic.json is
+    stamped with it)."""
     import hashlib
+    from cpuvoxelraycaster_amd import build
     h = hashlib.sha256()
     for f in KERNEL_SOURCES:
         with open(os.path.join(ROOT, "cpuvoxelraycaster_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
+    h.update(" ".join(build.FLAGS).encode())
     return h.hexdigest()[:16]
 
 
@@ -615,8 +618,11 @@ def main():
         # passes recorded in profiles/traffic.json -- only when that record was taken on THIS tree's kernel sources
         # (the stage-synchronous kernel has a specialisation for the pinhole camera, see csrc/vrc_kernels.hip launch_render)
         pinhole = cam.aperture == 0.0 and math.copysign(1.0, cam.aperture) > 0 and 1e-30 <= cam.focal_length < float("inf")
+        # (whole-spp work units select the 8-waves-per-SIMD build of the one-bounce pinhole kernel, vrc_api.cpp render_impl)
+        wide = (pinhole and cfg.get("gi_bounces", 1) <= 1 and whole_spp_units and spp > 1 and depth <= 10
+                and not (args.tuning and 0 < int(args.tuning.split(",")[0]) < 8))
         sync_kernel_name = (("k_render_sync_pinhole" if pinhole else "k_render_sync") + ("" if cfg.get("gi_bounces", 1) <= 1 else "2")
-                            + ("_resolved" if fused else ""))
+                            + ("_resolved" if fused else "") + ("_w8" if wide else ""))
         rec, why = pmc_record(f"{args.config}_n{world}" + ("" if F > 1 else "_inflight1")) if args.kernel == 2 else (None, "PMC record exists for k_render_sync only")
         traffic = rec["traffic_bytes"] if rec else None
         roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",

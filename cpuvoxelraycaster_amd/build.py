@@ -11,9 +11,12 @@ HEADERS = ["vrc_device.h", "vrc_walk.h", "vrc_internal.h", os.path.join("..", ".
 # -ffp-contract=off: hipcc fuses a*b+c into v_fma_f32 by default, which changes
 # which voxel a ray hits.  Correctly rounded f32 divide and
 # sqrt are hipcc's default; stated explicitly because parity depends on them.
+# -fno-slp-vectorize: hipcc packs pairs of scalar f32 operations into v_pk_* and keeps the pairs live, which costs a
+# third more register spills in the frame kernels for nothing (a packed op issues at the cost of two): 0.6-4 % on every
+# BASELINE configuration (tools/ab_variants.sh).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
          "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt",
-         "-fno-fast-math", "-Wall", "-Wno-unused-result"]
+         "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wno-unused-result"]
 
 
 STAMP = LIB + ".flags"   # the flags the library was built with: an experiment build is never mistaken for the product

@@ -605,6 +605,13 @@ int render_impl(vrc_renderer* r, const vrc_camera* cam, const vrc_frame_params* 
         const uint32_t lds = (s->depth - 1) * 2048u + 1536u;
         const uint32_t fit = 163840u / lds;
         bpc = vrc::sync_max_blocks_per_cu();          // its own default: as many as registers allow
+        // whole-spp work units (set by a host that keeps frames in flight): the pinhole kernel's 8-waves-per-SIMD build
+        const bool whole_spp = a.p.use_samples && a.p.spp > 1 && tuning.sample_chunk >= a.p.spp;
+        if (whole_spp && a.p.gi_bounces <= 1 && vrc::camera_is_pinhole(a.cam) && vrc::sync_wide_blocks_per_cu() <= fit &&
+            !(tuning.blocks_per_cu_set && tuning.blocks_per_cu < vrc::sync_wide_blocks_per_cu())) {
+            a.wide = 1u;
+            bpc = vrc::sync_wide_blocks_per_cu();
+        }
         if (tuning.blocks_per_cu_set && tuning.blocks_per_cu < bpc) bpc = tuning.blocks_per_cu;
         if (bpc > fit) bpc = fit;
     }

@@ -829,6 +829,7 @@ k_render_tile(const FrameArgs a)
 #ifndef VRC_SYNC_MIN_WAVES
 #define VRC_SYNC_MIN_WAVES 6
 #endif
+#define VRC_SYNC_WIDE_WAVES 8
 
 #ifdef VRC_PROBE
 __device__ __forceinline__ uint32_t probe_wave_max(uint32_t v)
@@ -1303,19 +1304,22 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
 // kernels: gi_chain is straight-line code there, which is worth a third of the register spills.  The ..._resolved
 // kernels are the same four with the fused resolve (vrc_render_frame_resolved) compiled in; the plain ones do not
 // carry its code or its arguments' registers.
-#define VRC_SYNC_KERNEL(name, PINHOLE, ONE_BOUNCE, FUSED)                                          \
-    extern "C" __global__ void __launch_bounds__(VRC_RENDER_BLOCK, VRC_SYNC_MIN_WAVES) name(const FrameArgs a) \
+#define VRC_SYNC_KERNEL(name, PINHOLE, ONE_BOUNCE, FUSED, WAVES)                                   \
+    extern "C" __global__ void __launch_bounds__(VRC_RENDER_BLOCK, WAVES) name(const FrameArgs a)  \
     {                                                                                              \
         render_sync_body<PINHOLE, ONE_BOUNCE, FUSED>(a);                                           \
     }
-VRC_SYNC_KERNEL(k_render_sync, false, true, false)
-VRC_SYNC_KERNEL(k_render_sync2, false, false, false)
-VRC_SYNC_KERNEL(k_render_sync_pinhole, true, true, false)
-VRC_SYNC_KERNEL(k_render_sync_pinhole2, true, false, false)
-VRC_SYNC_KERNEL(k_render_sync_resolved, false, true, true)
-VRC_SYNC_KERNEL(k_render_sync2_resolved, false, false, true)
-VRC_SYNC_KERNEL(k_render_sync_pinhole_resolved, true, true, true)
-VRC_SYNC_KERNEL(k_render_sync_pinhole2_resolved, true, false, true)
+VRC_SYNC_KERNEL(k_render_sync, false, true, false, VRC_SYNC_MIN_WAVES)
+VRC_SYNC_KERNEL(k_render_sync2, false, false, false, VRC_SYNC_MIN_WAVES)
+VRC_SYNC_KERNEL(k_render_sync_pinhole, true, true, false, VRC_SYNC_MIN_WAVES)
+VRC_SYNC_KERNEL(k_render_sync_pinhole2, true, false, false, VRC_SYNC_MIN_WAVES)
+VRC_SYNC_KERNEL(k_render_sync_resolved, false, true, true, VRC_SYNC_MIN_WAVES)
+VRC_SYNC_KERNEL(k_render_sync2_resolved, false, false, true, VRC_SYNC_MIN_WAVES)
+VRC_SYNC_KERNEL(k_render_sync_pinhole_resolved, true, true, true, VRC_SYNC_MIN_WAVES)
+VRC_SYNC_KERNEL(k_render_sync_pinhole2_resolved, true, false, true, VRC_SYNC_MIN_WAVES)
+// the one-bounce pinhole kernels at 8 waves per SIMD, for launches that overlap (vrc_internal.h: sync_wide_blocks_per_cu)
+VRC_SYNC_KERNEL(k_render_sync_pinhole_w8, true, true, false, VRC_SYNC_WIDE_WAVES)
+VRC_SYNC_KERNEL(k_render_sync_pinhole_resolved_w8, true, true, true, VRC_SYNC_WIDE_WAVES)
 #undef VRC_SYNC_KERNEL
 
 // ---------------------------------------------------------------------------
@@ -1492,6 +1496,22 @@ hipError_t launch_grid_cast(const uint8_t* cells, int X, int Y, int Z, uint64_t 
 uint32_t tile_wave_lds_bytes() { return TILE_WAVE_LDS; }
 uint32_t tile_max_blocks_per_cu() { return VRC_TILE_MIN_WAVES; }
 uint32_t sync_max_blocks_per_cu() { return VRC_SYNC_MIN_WAVES; }
+uint32_t sync_wide_blocks_per_cu() { return VRC_SYNC_WIDE_WAVES; }
+
+bool camera_is_pinhole(const vrc_camera& cam)
+{
+    // Pinhole camera (aperture exactly +0, the reference's default): rand_vec = 0 * getRand() is +-0, which changes
+    // neither focal_point - rand_vec (focal_point.x / .y are never -0 when focal_length >= 1e-30: lens.x / .y are +0
+    // or non-zero, camera_controller.hpp:36-42) nor, after the `+ 1`, the origin -- so the two lens draws and the
+    // products with them are skipped.  Any other aperture or focal_length takes the general kernel.
+    uint32_t ap_bits;
+    memcpy(&ap_bits, &cam.aperture, 4);
+    bool pinhole = ap_bits == 0u && cam.focal_length >= 1e-30f && cam.focal_length < __builtin_inff();
+#ifdef VRC_NO_PINHOLE_KERNEL   // A/B builds only
+    pinhole = false;
+#endif
+    return pinhole;
+}
 
 hipError_t launch_render(const FrameArgs& a, uint32_t grid_blocks, int kernel, hipStream_t st)
 {
@@ -1503,18 +1523,11 @@ hipError_t launch_render(const FrameArgs& a, uint32_t grid_blocks, int kernel, h
         hipLaunchKernelGGL(k_render_tile, dim3(grid_blocks), dim3(VRC_RENDER_BLOCK), lds, st, a);
     } else {
         const size_t lds = (size_t)(a.depth - 1) * VRC_RENDER_BLOCK * sizeof(uint2) + 1536;
-        // Pinhole camera (aperture exactly +0, the reference's default): rand_vec = 0 * getRand() is +-0, which changes
-        // neither focal_point - rand_vec (focal_point.x / .y are never -0 when focal_length >= 1e-30: lens.x / .y are +0
-        // or non-zero, camera_controller.hpp:36-42) nor, after the `+ 1`, the origin -- so the two lens draws and the
-        // products with them are skipped.  Any other aperture or focal_length takes the general kernel.
-        uint32_t ap_bits;
-        memcpy(&ap_bits, &a.cam.aperture, 4);
-        bool pinhole = ap_bits == 0u && a.cam.focal_length >= 1e-30f && a.cam.focal_length < __builtin_inff();
-#ifdef VRC_NO_PINHOLE_KERNEL   // A/B builds only
-        pinhole = false;
-#endif
+        const bool pinhole = camera_is_pinhole(a.cam);
         const bool one = a.p.gi_bounces <= 1u, fused = a.fused_resolve != 0u;
+        const bool wide = a.wide != 0u && pinhole && one;
         void (*kernel_fn)(const FrameArgs) =
+            wide    ? (fused ? k_render_sync_pinhole_resolved_w8 : k_render_sync_pinhole_w8) :
             pinhole ? (one ? (fused ? k_render_sync_pinhole_resolved : k_render_sync_pinhole)
                            : (fused ? k_render_sync_pinhole2_resolved : k_render_sync_pinhole2))
                     : (one ? (fused ? k_render_sync_resolved : k_render_sync)
