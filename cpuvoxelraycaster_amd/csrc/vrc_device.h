@@ -299,7 +299,27 @@ __device__ __forceinline__ void ray_run(Ray& r, bool active, const uint2* __rest
     while (active) active = ray_step<STRIDE, LOD_MODE != 0>(r, nodes, stk, depth, coef, bias);
 #else
     static_assert(STRIDE == 256, "vrc_walk.h addresses LDS stack rows of 256 lanes");
-    ray_walk<LOD_MODE>(r, active, nodes, stk, depth, coef, bias);
+    ray_walk<LOD_MODE, true>(r, active, nodes, stk, depth, coef, bias);
+#endif
+}
+
+// The same for callers that only total the iterations (the stage-synchronous frame kernels): adds the loop iterations
+// of this call to `n_steps` -- the wave's total lands in the first of the lanes that ran, the sum over lanes is what
+// counts -- and leaves r.complexity alone.
+template <int STRIDE, int LOD_MODE>
+__device__ __forceinline__ void ray_run_total(Ray& r, bool active, const uint2* __restrict__ nodes, uint2* stk,
+                                              int depth, float coef, float bias, uint32_t& n_steps)
+{
+#if defined(VRC_WALK_CPP) || defined(VRC_PROBE)
+    ray_run<STRIDE, LOD_MODE>(r, active, nodes, stk, depth, coef, bias);
+    n_steps += r.complexity;
+#else
+    static_assert(STRIDE == 256, "vrc_walk.h addresses LDS stack rows of 256 lanes");
+    const uint32_t wave_steps = ray_walk<LOD_MODE, false>(r, active, nodes, stk, depth, coef, bias);
+    // lanes that ran = the lanes inside ray_walk's `if (active)`; the first of them books the wave's iterations
+    if (active && __builtin_amdgcn_mbcnt_hi((uint32_t)(__ballot(active) >> 32),
+                                            __builtin_amdgcn_mbcnt_lo((uint32_t)__ballot(active), 0u)) == 0u)
+        n_steps += wave_steps;
 #endif
 }
 

@@ -877,8 +877,8 @@ __device__ __forceinline__ float gi_chain(const uint2* __restrict__ nodes, uint2
         const float dot_gi = dot3(dx, dy, dz, base_nx, base_ny, base_nz);   // :193
         if (level == 0u) dgi[0] = dot_gi; else dgi[1] = dot_gi;
         active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
-        ray_run<VRC_RENDER_BLOCK, 1>(r, active, nodes, stk, depth, 0.5f, 0.0f);   // :194
-        n_rays += 1u; n_steps += r.complexity;
+        ray_run_total<VRC_RENDER_BLOCK, 1>(r, active, nodes, stk, depth, 0.5f, 0.0f, n_steps);   // :194
+        n_rays += 1u;
         Hit g;
         ray_finish(r, depth, ox, oy, oz, dx, dy, dz, g);
         chain = false;
@@ -891,8 +891,8 @@ __device__ __forceinline__ float gi_chain(const uint2* __restrict__ nodes, uint2
             const float dotl = dot3(g.nx, g.ny, g.nz, dx, dy, dz);         // :200
             const float contrib = 1000000.0f * smin(0.5f, smax(0.0f, dotl) * dot_gi);   // :201
             active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
-            ray_run<VRC_RENDER_BLOCK, 1>(r, active, nodes, stk, depth, 0.5f, 0.0f);   // :198
-            n_rays += 1u; n_steps += r.complexity;
+            ray_run_total<VRC_RENDER_BLOCK, 1>(r, active, nodes, stk, depth, 0.5f, 0.0f, n_steps);   // :198
+            n_rays += 1u;
             if (!r.kind) { if (level == 0u) acc[0] += contrib; else acc[1] += contrib; }
             if (level + 1u < gi_bounces) {
                 base_px = g.px; base_py = g.py; base_pz = g.pz;
@@ -1083,8 +1083,13 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
                 r = r0;
                 for (uint32_t k = 0; k < n_walks; ++k) {                            // raycaster.hpp:131, once per sample
                     r = r0;
-                    ray_run<VRC_RENDER_BLOCK, 0>(r, active, nodes, stk, depth, 0.0f, 0.0f);
-                    n_rays += 1u; n_steps += r.complexity;
+                    if (a.prim) {                                                   // the capture records the ray's own complexity
+                        ray_run<VRC_RENDER_BLOCK, 0>(r, active, nodes, stk, depth, 0.0f, 0.0f);
+                        n_steps += r.complexity;
+                    } else {
+                        ray_run_total<VRC_RENDER_BLOCK, 0>(r, active, nodes, stk, depth, 0.0f, 0.0f, n_steps);
+                    }
+                    n_rays += 1u;
                 }
                 Hit h;
                 ray_finish(r, depth, ox, oy, oz, dx, dy, dz, h);
@@ -1111,8 +1116,8 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
                     active = ray_setup(r0, root, ox, oy, oz, dx, dy, dz);
                     for (uint32_t k = n_shadow_walks; k--;) {
                         r = r0;
-                        ray_run<VRC_RENDER_BLOCK, 0>(r, active, nodes, stk, depth, 0.0f, 0.0f);
-                        n_rays += 1u; n_steps += r.complexity;
+                        ray_run_total<VRC_RENDER_BLOCK, 0>(r, active, nodes, stk, depth, 0.0f, 0.0f, n_steps);
+                        n_rays += 1u;
                     }
                     if (!r.kind) light_intensity = lit;                                      // :155-157
                 }
@@ -1168,8 +1173,13 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
                     float oz = (a.cam.position[2] + wz) * inv_size + 1.0f;
                     Ray r;
                     bool active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
-                    ray_run<VRC_RENDER_BLOCK, 0>(r, active, nodes, stk, depth, 0.0f, 0.0f);
-                    n_rays += 1u; n_steps += r.complexity; VRC_PROBE_WALK(r, 0)
+                    if (a.prim) {                                                   // the capture records the ray's own complexity
+                        ray_run<VRC_RENDER_BLOCK, 0>(r, active, nodes, stk, depth, 0.0f, 0.0f);
+                        n_steps += r.complexity;
+                    } else {
+                        ray_run_total<VRC_RENDER_BLOCK, 0>(r, active, nodes, stk, depth, 0.0f, 0.0f, n_steps);
+                    }
+                    n_rays += 1u; VRC_PROBE_WALK(r, 0)
                     Hit h;
                     ray_finish(r, depth, ox, oy, oz, dx, dy, dz, h);                   // raycaster.hpp:131
 #ifndef VRC_PROBE
@@ -1193,8 +1203,8 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
                             normalize3(dx, dy, dz);
                             const float lit = smax(0.0f, dot3(dx, dy, dz, h.nx, h.ny, h.nz));       // :156
                             active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
-                            ray_run<VRC_RENDER_BLOCK, 0>(r, active, nodes, stk, depth, 0.0f, 0.0f);
-                            n_rays += 1u; n_steps += r.complexity; VRC_PROBE_WALK(r, 1)
+                            ray_run_total<VRC_RENDER_BLOCK, 0>(r, active, nodes, stk, depth, 0.0f, 0.0f, n_steps);
+                            n_rays += 1u; VRC_PROBE_WALK(r, 1)
                             if (!r.kind) light_intensity = lit;                                  // :155-157
                         }
                         // raycaster.hpp:161,169-207 GI (+ the nested second bounce of the extension)

@@ -35,6 +35,14 @@ namespace vrc {
     "s_and_b64 %[sin], %[stm], vcc\n"
 #define VRC_WALK_TMAX_CMP "v_min_f32_e32 v43, v43, %[tc]\n"
 
+// HitPoint::complexity (:73).  Per lane (the per-ray operator returns it, the primary-hit capture records it) or, for the
+// frame kernels, which only need the launch's total: the lanes at the loop top counted by the scalar unit (a lane's
+// complexity is the number of loop tops it was live at) -- one VALU instruction per iteration less in an issue-bound loop.
+#define VRC_WALK_COUNT_LANE "v_add_u32_e32 %[cmpl], 1, %[cmpl]\n"
+#define VRC_WALK_COUNT_WAVE                                                                     \
+    "s_bcnt1_i32_b64 %[sb], exec\n"                                                             \
+    "s_add_u32 %[ssteps], %[ssteps], %[sb]\n"
+
 // LOD_MODE: 0 = no LOD test (coef == bias == 0), 1 = bias == 0 (x + 0 does not change the comparison),
 // 2 = general.
 #define VRC_WALK_LOD_NONE ""
@@ -57,7 +65,7 @@ namespace vrc {
 // v32:33 t_coef.xy  v34 t_coef.z  v35 t_offset.z  v36:37 t_offset.xy  v38:39 pos.xy  v40 pos.z
 // v41 t_min  v42:43 {parent_id, t_max} (the stack entry)  v44 scale_f (v45 h)  v46:47 node
 // v48:49 c.xy  v52 c.z  v50:51 / v53 per-axis step / half-point scratch
-#define VRC_WALK_ASM(SPANPART, LODPART, TMAXPART)                                                                   \
+#define VRC_WALK_ASM(SPANPART, LODPART, TMAXPART, COUNTPART)                                                                \
     "s_mov_b64 %[sentry], exec\n"                                                               \
     "s_mov_b64 %[sleaf], 0\n"                                                                   \
     "s_mov_b64 %[slod], 0\n"                                                                    \
@@ -67,7 +75,7 @@ namespace vrc {
     "s_cmpk_gt_u32 %[siter], 0xffff\n"          /* safety net, MAX_ITERATIONS */                \
     "s_cbranch_scc1 Lwalk_done%=\n"                                                             \
     "s_add_u32 %[siter], %[siter], 1\n"                                                         \
-    "v_add_u32_e32 %[cmpl], 1, %[cmpl]\n"       /* :73 */                                       \
+    COUNTPART                                   /* :73 ++complexity */                          \
     "v_xor_b32_e32 %[cs], %[co], %[mirror]\n"   /* :79 child_shift */                           \
     "v_pk_mul_f32 v[48:49], v[38:39], v[32:33]\n" /* :76 */                                     \
     "v_mul_f32_e32 v52, v40, v34\n"                                                             \
@@ -182,24 +190,26 @@ namespace vrc {
 
 // Runs the walk for the lanes with `active` set (the others keep their state: kind 0, complexity 0).
 // `stk` = this lane's column of the LDS stack, rows of 256 lanes (2 KiB apart).
-template <int LOD_MODE>
-__device__ __forceinline__ void ray_walk(Ray& r, bool active, const uint2* __restrict__ nodes, uint2* stk,
-                                         int depth, float coef, float bias)
+// COUNT_LANE: r.complexity is maintained (per lane); otherwise it is left alone and the return value is the number of
+// loop iterations all the wave's lanes executed in this call together (the same value in every lane; 0 for `!active`).
+template <int LOD_MODE, bool COUNT_LANE>
+__device__ __forceinline__ uint32_t ray_walk(Ray& r, bool active, const uint2* __restrict__ nodes, uint2* stk,
+                                             int depth, float coef, float bias)
 {
-    if (!active) return;
+    if (!active) return 0u;
     // LDS byte address of slot 0 minus the rows of the scales that have no slot (slot = scale - depth_off - 1)
     const uint32_t stkb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint2*)stk
                           - (uint32_t)(SVO_MAX - depth + 1) * 2048u;
     const uint32_t sfc = 104u << 23;            // (scale - 23 + 127) << 23 = (scale << 23) + (104 << 23)
     uint64_t sentry, sleaf, slod, srun, sin_, schild, stm, st;   // schild / stm double as the x / y step masks of the advance
-    uint32_t siter, cs, m, t, t2, kind = 0u;
+    uint32_t siter, cs, m, t, t2, kind = 0u, ssteps = 0u, sb;
     float tc;
     float tcx = r.tcx, tcy = r.tcy, tcz = r.tcz, tox = r.tox, toy = r.toy, toz = r.toz;
     float px = r.px, py = r.py, pz = r.pz, t_min = r.t_min, t_max = r.t_max, sf = r.scale_f, h = r.h;
     uint32_t pid = r.parent_id, ndx = r.nd.x, ndy = r.nd.y;
-    uint32_t scale = (uint32_t)r.scale, co = r.child_offset, normal = r.normal, cmpl = r.complexity;
-#define VRC_WALK_OPERANDS                                                                                         \
-        : [kind] "+v"(kind), [cmpl] "+v"(cmpl), [scale] "+v"(scale), [co] "+v"(co), [normal] "+v"(normal),            \
+    uint32_t scale = (uint32_t)r.scale, co = r.child_offset, normal = r.normal, cmpl = COUNT_LANE ? r.complexity : 0u;
+#define VRC_WALK_OPERANDS(COUNT_OPERANDS)                                                                         \
+        : [kind] "+v"(kind), COUNT_OPERANDS, [scale] "+v"(scale), [co] "+v"(co), [normal] "+v"(normal),              \
           "+{v38}"(px), "+{v39}"(py), "+{v40}"(pz), "+{v41}"(t_min), "+{v42}"(pid), "+{v43}"(t_max),                  \
           "+{v44}"(sf), "+{v45}"(h), "+{v46}"(ndx), "+{v47}"(ndy),                                                    \
           [sentry] "=&s"(sentry), [sleaf] "=&s"(sleaf), [slod] "=&s"(slod), [srun] "=&s"(srun), [sin] "=&s"(sin_),    \
@@ -208,15 +218,27 @@ __device__ __forceinline__ void ray_walk(Ray& r, bool active, const uint2* __res
         : "{v32}"(tcx), "{v33}"(tcy), "{v34}"(tcz), "{v35}"(toz), "{v36}"(tox), "{v37}"(toy),                         \
           [mirror] "v"(r.mirror), [stkb] "v"(stkb), [nodes] "s"(nodes), [sfc] "s"(sfc), [coef] "v"(coef), [bias] "v"(bias) \
         : "v48", "v49", "v50", "v51", "v52", "v53", "vcc", "scc", "memory"
-    if (LOD_MODE == 0) asm volatile(VRC_WALK_ASM(VRC_WALK_SPAN_MIN, VRC_WALK_LOD_NONE, VRC_WALK_TMAX_MIN) VRC_WALK_OPERANDS);
-    else if (LOD_MODE == 1) asm volatile(VRC_WALK_ASM(VRC_WALK_SPAN_CMP, VRC_WALK_LOD_COEF, VRC_WALK_TMAX_CMP) VRC_WALK_OPERANDS);
-    else asm volatile(VRC_WALK_ASM(VRC_WALK_SPAN_CMP, VRC_WALK_LOD_FULL, VRC_WALK_TMAX_CMP) VRC_WALK_OPERANDS);
+#define VRC_WALK_OPS_LANE [cmpl] "+v"(cmpl)
+#define VRC_WALK_OPS_WAVE [ssteps] "+s"(ssteps), [sb] "=&s"(sb)
+    if (COUNT_LANE) {
+        if (LOD_MODE == 0) asm volatile(VRC_WALK_ASM(VRC_WALK_SPAN_MIN, VRC_WALK_LOD_NONE, VRC_WALK_TMAX_MIN, VRC_WALK_COUNT_LANE) VRC_WALK_OPERANDS(VRC_WALK_OPS_LANE));
+        else if (LOD_MODE == 1) asm volatile(VRC_WALK_ASM(VRC_WALK_SPAN_CMP, VRC_WALK_LOD_COEF, VRC_WALK_TMAX_CMP, VRC_WALK_COUNT_LANE) VRC_WALK_OPERANDS(VRC_WALK_OPS_LANE));
+        else asm volatile(VRC_WALK_ASM(VRC_WALK_SPAN_CMP, VRC_WALK_LOD_FULL, VRC_WALK_TMAX_CMP, VRC_WALK_COUNT_LANE) VRC_WALK_OPERANDS(VRC_WALK_OPS_LANE));
+    } else {
+        if (LOD_MODE == 0) asm volatile(VRC_WALK_ASM(VRC_WALK_SPAN_MIN, VRC_WALK_LOD_NONE, VRC_WALK_TMAX_MIN, VRC_WALK_COUNT_WAVE) VRC_WALK_OPERANDS(VRC_WALK_OPS_WAVE));
+        else if (LOD_MODE == 1) asm volatile(VRC_WALK_ASM(VRC_WALK_SPAN_CMP, VRC_WALK_LOD_COEF, VRC_WALK_TMAX_CMP, VRC_WALK_COUNT_WAVE) VRC_WALK_OPERANDS(VRC_WALK_OPS_WAVE));
+        else asm volatile(VRC_WALK_ASM(VRC_WALK_SPAN_CMP, VRC_WALK_LOD_FULL, VRC_WALK_TMAX_CMP, VRC_WALK_COUNT_WAVE) VRC_WALK_OPERANDS(VRC_WALK_OPS_WAVE));
+    }
+#undef VRC_WALK_OPS_LANE
+#undef VRC_WALK_OPS_WAVE
 #undef VRC_WALK_OPERANDS
     r.px = px; r.py = py; r.pz = pz; r.t_min = t_min; r.t_max = t_max; r.scale_f = sf; r.h = h;
     r.parent_id = pid; r.nd = make_uint2(ndx, ndy);
-    r.scale = (int)scale; r.child_offset = co; r.normal = normal; r.complexity = cmpl;
+    r.scale = (int)scale; r.child_offset = co; r.normal = normal;
+    if (COUNT_LANE) r.complexity = cmpl;
     r.kind = kind;
     r.shift = co ^ r.mirror;                    // child_shift of the child that was hit (unused on a miss)
+    return ssteps;
 }
 
 }  // namespace vrc
