@@ -602,7 +602,7 @@ int render_impl(vrc_renderer* r, const vrc_camera* cam, const vrc_frame_params* 
         if (bpc > fit) bpc = fit;
         if (bpc > vrc::tile_max_blocks_per_cu()) bpc = vrc::tile_max_blocks_per_cu();
     } else if (tuning.kernel == VRC_KERNEL_SYNC) {
-        const uint32_t lds = (s->depth - 1) * 2048u + 1536u;
+        const uint32_t lds = (s->depth - 1) * 2048u + 1536u + 128u;
         const uint32_t fit = 163840u / lds;
         bpc = vrc::sync_max_blocks_per_cu();          // its own default: as many as registers allow
         // whole-spp work units (set by a host that keeps frames in flight): the pinhole kernel's 8-waves-per-SIMD build

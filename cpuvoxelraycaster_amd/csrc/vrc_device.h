@@ -303,23 +303,39 @@ __device__ __forceinline__ void ray_run(Ray& r, bool active, const uint2* __rest
 #endif
 }
 
-// The same for callers that only total the iterations (the stage-synchronous frame kernels): adds the loop iterations
-// of this call to `n_steps` -- the wave's total lands in the first of the lanes that ran, the sum over lanes is what
-// counts -- and leaves r.complexity alone.
+// The same for callers that only total rays and iterations (the stage-synchronous frame kernels): books the call in the
+// wave's LDS counters -- ctr[0] += loop iterations of all lanes, ctr[1] += lanes that cast a ray -- and leaves
+// r.complexity alone.  One no-return LDS add pair by the first lane that ran; no per-lane counter stays live.
+__device__ __forceinline__ void book_walk(unsigned long long* ctr, uint32_t wave_steps)
+{
+    // every lane that makes the call casts a ray (one that ray_setup rejected is a ray of complexity 0, as in the oracle)
+    const unsigned long long here = __ballot(true);
+    if (__builtin_amdgcn_mbcnt_hi((uint32_t)(here >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)here, 0u)) == 0u) {
+        __hip_atomic_fetch_add(ctr + 0, (unsigned long long)wave_steps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        __hip_atomic_fetch_add(ctr + 1, (unsigned long long)__popcll(here), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+}
+
+// ... and for a walk that kept per-lane complexities (primary-hit capture on): every lane books its own
+__device__ __forceinline__ void book_walk_lanes(unsigned long long* ctr, uint32_t complexity)
+{
+    const unsigned long long here = __ballot(true);
+    __hip_atomic_fetch_add(ctr + 0, (unsigned long long)complexity, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    if (__builtin_amdgcn_mbcnt_hi((uint32_t)(here >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)here, 0u)) == 0u)
+        __hip_atomic_fetch_add(ctr + 1, (unsigned long long)__popcll(here), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+
 template <int STRIDE, int LOD_MODE>
 __device__ __forceinline__ void ray_run_total(Ray& r, bool active, const uint2* __restrict__ nodes, uint2* stk,
-                                              int depth, float coef, float bias, uint32_t& n_steps)
+                                              int depth, float coef, float bias, unsigned long long* ctr)
 {
 #if defined(VRC_WALK_CPP) || defined(VRC_PROBE)
     ray_run<STRIDE, LOD_MODE>(r, active, nodes, stk, depth, coef, bias);
-    n_steps += r.complexity;
+    book_walk_lanes(ctr, r.complexity);
 #else
     static_assert(STRIDE == 256, "vrc_walk.h addresses LDS stack rows of 256 lanes");
     const uint32_t wave_steps = ray_walk<LOD_MODE, false>(r, active, nodes, stk, depth, coef, bias);
-    // lanes that ran = the lanes inside ray_walk's `if (active)`; the first of them books the wave's iterations
-    if (active && __builtin_amdgcn_mbcnt_hi((uint32_t)(__ballot(active) >> 32),
-                                            __builtin_amdgcn_mbcnt_lo((uint32_t)__ballot(active), 0u)) == 0u)
-        n_steps += wave_steps;
+    book_walk(ctr, wave_steps);
 #endif
 }
 

@@ -829,7 +829,9 @@ k_render_tile(const FrameArgs a)
 #ifndef VRC_SYNC_MIN_WAVES
 #define VRC_SYNC_MIN_WAVES 6
 #endif
+#ifndef VRC_SYNC_WIDE_WAVES
 #define VRC_SYNC_WIDE_WAVES 8
+#endif
 
 #ifdef VRC_PROBE
 __device__ __forceinline__ uint32_t probe_wave_max(uint32_t v)
@@ -850,7 +852,7 @@ __device__ __forceinline__ float gi_chain(const uint2* __restrict__ nodes, uint2
                                           const float n_normalizer, const float lx, const float ly, const float lz,
                                           const uint32_t gi_bounces_rt, const uint32_t seed, const uint32_t fr, const uint32_t pix,
                                           float base_px, float base_py, float base_pz, float base_nx, float base_ny, float base_nz,
-                                          uint32_t& n_rays, uint32_t& n_steps)
+                                          unsigned long long* ctr)
 {
     const uint32_t gi_bounces = ONE_BOUNCE ? 1u : gi_bounces_rt;
     Ray r;
@@ -877,8 +879,7 @@ __device__ __forceinline__ float gi_chain(const uint2* __restrict__ nodes, uint2
         const float dot_gi = dot3(dx, dy, dz, base_nx, base_ny, base_nz);   // :193
         if (level == 0u) dgi[0] = dot_gi; else dgi[1] = dot_gi;
         active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
-        ray_run_total<VRC_RENDER_BLOCK, 1>(r, active, nodes, stk, depth, 0.5f, 0.0f, n_steps);   // :194
-        n_rays += 1u;
+        ray_run_total<VRC_RENDER_BLOCK, 1>(r, active, nodes, stk, depth, 0.5f, 0.0f, ctr);   // :194
         Hit g;
         ray_finish(r, depth, ox, oy, oz, dx, dy, dz, g);
         chain = false;
@@ -891,8 +892,7 @@ __device__ __forceinline__ float gi_chain(const uint2* __restrict__ nodes, uint2
             const float dotl = dot3(g.nx, g.ny, g.nz, dx, dy, dz);         // :200
             const float contrib = 1000000.0f * smin(0.5f, smax(0.0f, dotl) * dot_gi);   // :201
             active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
-            ray_run_total<VRC_RENDER_BLOCK, 1>(r, active, nodes, stk, depth, 0.5f, 0.0f, n_steps);   // :198
-            n_rays += 1u;
+            ray_run_total<VRC_RENDER_BLOCK, 1>(r, active, nodes, stk, depth, 0.5f, 0.0f, ctr);   // :198
             if (!r.kind) { if (level == 0u) acc[0] += contrib; else acc[1] += contrib; }
             if (level + 1u < gi_bounces) {
                 base_px = g.px; base_py = g.py; base_pz = g.pz;
@@ -940,12 +940,16 @@ __device__ __forceinline__ uint32_t albedo_of(const uint8_t* tex, const Hit& h)
 template <bool PINHOLE, bool ONE_BOUNCE, bool FUSED>
 __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
 {
-    extern __shared__ uint2 lds_dyn[];   // [depth-1][256] stack | 1536 B textures
+    extern __shared__ uint2 lds_dyn[];   // [depth-1][256] stack | 1536 B textures | 4 waves x 4 counters
     uint2* stk = lds_dyn + threadIdx.x;
     uint8_t* tex = reinterpret_cast<uint8_t*>(lds_dyn + (a.depth - 1) * VRC_RENDER_BLOCK);
     const uint32_t lane = threadIdx.x & 63u;
     for (uint32_t i = threadIdx.x; i < 1536u / 4u; i += VRC_RENDER_BLOCK)
         reinterpret_cast<uint32_t*>(tex)[i] = reinterpret_cast<const uint32_t*>(a.tex)[i];
+    // this wave's {loop iterations, rays, primary hits, pixel-samples}: booked per walk / per unit by one lane with
+    // no-return LDS adds, so that no per-lane counter is live across the walks (the kernel is at its register budget)
+    unsigned long long* const ctr = reinterpret_cast<unsigned long long*>(tex + 1536) + 4u * (threadIdx.x >> 6);
+    if (lane < 4u) ctr[lane] = 0ull;
     __syncthreads();
 
     const uint2* __restrict__ nodes = a.nodes;
@@ -985,7 +989,7 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
     const uint32_t head_units = head_tiles * cpt_head;
     const uint32_t n_units = head_units + tail_tiles * cpt_tail;
 
-    uint32_t n_rays = 0u, n_steps = 0u, n_hits = 0u, n_pix = 0u;
+    uint32_t n_hits = 0u, n_pix = 0u;     // per lane; the general kernel only (a lane's samples differ in their hits)
 
     // Work queue with 8 heads (one 128-byte line each): head q hands out units q, q+8, q+16, ...
     // A wave starts on the head of its workgroup's XCD group (blockIdx % 8: workgroups b and b+8
@@ -1085,11 +1089,10 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
                     r = r0;
                     if (a.prim) {                                                   // the capture records the ray's own complexity
                         ray_run<VRC_RENDER_BLOCK, 0>(r, active, nodes, stk, depth, 0.0f, 0.0f);
-                        n_steps += r.complexity;
+                        book_walk_lanes(ctr, r.complexity);
                     } else {
-                        ray_run_total<VRC_RENDER_BLOCK, 0>(r, active, nodes, stk, depth, 0.0f, 0.0f, n_steps);
+                        ray_run_total<VRC_RENDER_BLOCK, 0>(r, active, nodes, stk, depth, 0.0f, 0.0f, ctr);
                     }
-                    n_rays += 1u;
                 }
                 Hit h;
                 ray_finish(r, depth, ox, oy, oz, dx, dy, dz, h);
@@ -1103,7 +1106,6 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
 #endif
                 if (h.hit) {
                     hit = true;
-                    n_hits += n_samples;
                     albedo = albedo_of(tex, h);                                     // raycaster.hpp:141-145
                     hpx = h.px; hpy = h.py; hpz = h.pz; hnx = h.nx; hny = h.ny; hnz = h.nz;
                     // raycaster.hpp:139,150-158 shadow ray(s): the reference re-casts the identical ray
@@ -1116,8 +1118,7 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
                     active = ray_setup(r0, root, ox, oy, oz, dx, dy, dz);
                     for (uint32_t k = n_shadow_walks; k--;) {
                         r = r0;
-                        ray_run_total<VRC_RENDER_BLOCK, 0>(r, active, nodes, stk, depth, 0.0f, 0.0f, n_steps);
-                        n_rays += 1u;
+                        ray_run_total<VRC_RENDER_BLOCK, 0>(r, active, nodes, stk, depth, 0.0f, 0.0f, ctr);
                     }
                     if (!r.kind) light_intensity = lit;                                      // :155-157
                 }
@@ -1130,11 +1131,17 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
                         float gi_intensity = 0.0f;
                         if (a.p.use_gi)
                             gi_intensity = gi_chain<ONE_BOUNCE>(nodes, stk, root, depth, n_normalizer, lx, ly, lz, gi_bounces, a.p.seed,
-                                                    a.p.frame_index + sample, pix, hpx, hpy, hpz, hnx, hny, hnz, n_rays, n_steps);
+                                                    a.p.frame_index + sample, pix, hpx, hpy, hpz, hnx, hny, hnz, ctr);
                         color = color_mult(albedo, smin(1.0f, smax(0.0f, light_intensity + gi_intensity)));   // :163
                     }
-                    n_pix += 1u;
                     sink_sample(a, pix, color, acc_r, acc_g, acc_b);
+                }
+            }
+            {   // the unit's primary hits and pixel-samples: a lane's samples all share the hit
+                const unsigned long long mv = __ballot(valid), mh = __ballot(hit);
+                if (lane == 0u) {
+                    __hip_atomic_fetch_add(ctr + 2, (unsigned long long)__popcll(mh) * n_samples, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    __hip_atomic_fetch_add(ctr + 3, (unsigned long long)__popcll(mv) * n_samples, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 }
             }
         } else {
@@ -1175,11 +1182,11 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
                     bool active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
                     if (a.prim) {                                                   // the capture records the ray's own complexity
                         ray_run<VRC_RENDER_BLOCK, 0>(r, active, nodes, stk, depth, 0.0f, 0.0f);
-                        n_steps += r.complexity;
+                        book_walk_lanes(ctr, r.complexity);
                     } else {
-                        ray_run_total<VRC_RENDER_BLOCK, 0>(r, active, nodes, stk, depth, 0.0f, 0.0f, n_steps);
+                        ray_run_total<VRC_RENDER_BLOCK, 0>(r, active, nodes, stk, depth, 0.0f, 0.0f, ctr);
                     }
-                    n_rays += 1u; VRC_PROBE_WALK(r, 0)
+                    VRC_PROBE_WALK(r, 0)
                     Hit h;
                     ray_finish(r, depth, ox, oy, oz, dx, dy, dz, h);                   // raycaster.hpp:131
 #ifndef VRC_PROBE
@@ -1203,15 +1210,15 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
                             normalize3(dx, dy, dz);
                             const float lit = smax(0.0f, dot3(dx, dy, dz, h.nx, h.ny, h.nz));       // :156
                             active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
-                            ray_run_total<VRC_RENDER_BLOCK, 0>(r, active, nodes, stk, depth, 0.0f, 0.0f, n_steps);
-                            n_rays += 1u; VRC_PROBE_WALK(r, 1)
+                            ray_run_total<VRC_RENDER_BLOCK, 0>(r, active, nodes, stk, depth, 0.0f, 0.0f, ctr);
+                            VRC_PROBE_WALK(r, 1)
                             if (!r.kind) light_intensity = lit;                                  // :155-157
                         }
                         // raycaster.hpp:161,169-207 GI (+ the nested second bounce of the extension)
                         float gi_intensity = 0.0f;
                         if (a.p.use_gi)
                             gi_intensity = gi_chain<ONE_BOUNCE>(nodes, stk, root, depth, n_normalizer, lx, ly, lz, gi_bounces, a.p.seed, fr, pix,
-                                                    h.px, h.py, h.pz, h.nx, h.ny, h.nz, n_rays, n_steps);
+                                                    h.px, h.py, h.pz, h.nx, h.ny, h.nz, ctr);
                         color = color_mult(albedo, smin(1.0f, smax(0.0f, light_intensity + gi_intensity)));   // :163
                     }
                     n_pix += 1u;
@@ -1292,19 +1299,18 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
         o[6] = __builtin_amdgcn_s_getreg((31 << 11) | 4); o[7] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
     }
 #endif
-    uint64_t s_rays = n_rays, s_steps = n_steps, s_hits = n_hits, s_pix = n_pix;
+    // per-lane counters (the general kernel's hits and pixel-samples) summed over the wave, plus the wave's LDS counters
+    uint64_t s_hits = n_hits, s_pix = n_pix;
     for (int off = 32; off > 0; off >>= 1) {
-        s_rays += __shfl_down(s_rays, off);
-        s_steps += __shfl_down(s_steps, off);
         s_hits += __shfl_down(s_hits, off);
         s_pix += __shfl_down(s_pix, off);
     }
     if (lane == 0u) {
         uint64_t* slot = a.stats + 4u * (blockIdx.x % VRC_STAT_SLOTS);
-        atomicAdd(reinterpret_cast<unsigned long long*>(slot + 0), (unsigned long long)s_rays);
-        atomicAdd(reinterpret_cast<unsigned long long*>(slot + 1), (unsigned long long)s_steps);
-        atomicAdd(reinterpret_cast<unsigned long long*>(slot + 2), (unsigned long long)s_hits);
-        atomicAdd(reinterpret_cast<unsigned long long*>(slot + 3), (unsigned long long)s_pix);
+        atomicAdd(reinterpret_cast<unsigned long long*>(slot + 0), ctr[1]);
+        atomicAdd(reinterpret_cast<unsigned long long*>(slot + 1), ctr[0]);
+        atomicAdd(reinterpret_cast<unsigned long long*>(slot + 2), (unsigned long long)s_hits + ctr[2]);
+        atomicAdd(reinterpret_cast<unsigned long long*>(slot + 3), (unsigned long long)s_pix + ctr[3]);
     }
 }
 
@@ -1532,7 +1538,7 @@ hipError_t launch_render(const FrameArgs& a, uint32_t grid_blocks, int kernel, h
         const size_t lds = (size_t)(a.depth - 1) * VRC_RENDER_BLOCK * sizeof(uint2) + 4 * TILE_WAVE_LDS + 1536;
         hipLaunchKernelGGL(k_render_tile, dim3(grid_blocks), dim3(VRC_RENDER_BLOCK), lds, st, a);
     } else {
-        const size_t lds = (size_t)(a.depth - 1) * VRC_RENDER_BLOCK * sizeof(uint2) + 1536;
+        const size_t lds = (size_t)(a.depth - 1) * VRC_RENDER_BLOCK * sizeof(uint2) + 1536 + 128;   // + the waves' counters
         const bool pinhole = camera_is_pinhole(a.cam);
         const bool one = a.p.gi_bounces <= 1u, fused = a.fused_resolve != 0u;
         const bool wide = a.wide != 0u && pinhole && one;

@@ -67,6 +67,7 @@ namespace vrc {
 // v48:49 c.xy  v52 c.z  v50:51 / v53 per-axis step / half-point scratch
 #define VRC_WALK_ASM(SPANPART, LODPART, TMAXPART, COUNTPART)                                                                \
     "s_mov_b64 %[sentry], exec\n"                                                               \
+    "s_and_b64 exec, exec, %[sact]\n"           /* the lanes with a ray to walk */              \
     "s_mov_b64 %[sleaf], 0\n"                                                                   \
     "s_mov_b64 %[slod], 0\n"                                                                    \
     "s_mov_b32 %[siter], 0\n"                                                                   \
@@ -191,12 +192,14 @@ namespace vrc {
 // Runs the walk for the lanes with `active` set (the others keep their state: kind 0, complexity 0).
 // `stk` = this lane's column of the LDS stack, rows of 256 lanes (2 KiB apart).
 // COUNT_LANE: r.complexity is maintained (per lane); otherwise it is left alone and the return value is the number of
-// loop iterations all the wave's lanes executed in this call together (the same value in every lane; 0 for `!active`).
+// loop iterations all the wave's lanes executed in this call together (the same value in every lane that made the call).
 template <int LOD_MODE, bool COUNT_LANE>
 __device__ __forceinline__ uint32_t ray_walk(Ray& r, bool active, const uint2* __restrict__ nodes, uint2* stk,
                                              int depth, float coef, float bias)
 {
-    if (!active) return 0u;
+    // (no branch around the loop for the lanes without a ray: the loop masks them itself, so that the SGPR results
+    // are the same for every lane that made the call)
+    const unsigned long long sact = __ballot(active);
     // LDS byte address of slot 0 minus the rows of the scales that have no slot (slot = scale - depth_off - 1)
     const uint32_t stkb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint2*)stk
                           - (uint32_t)(SVO_MAX - depth + 1) * 2048u;
@@ -216,7 +219,8 @@ __device__ __forceinline__ uint32_t ray_walk(Ray& r, bool active, const uint2* _
           [schild] "=&s"(schild), [stm] "=&s"(stm), [st] "=&s"(st),                                                   \
           [siter] "=&s"(siter), [cs] "=&v"(cs), [m] "=&v"(m), [t] "=&v"(t), [t2] "=&v"(t2), [tc] "=&v"(tc)            \
         : "{v32}"(tcx), "{v33}"(tcy), "{v34}"(tcz), "{v35}"(toz), "{v36}"(tox), "{v37}"(toy),                         \
-          [mirror] "v"(r.mirror), [stkb] "v"(stkb), [nodes] "s"(nodes), [sfc] "s"(sfc), [coef] "v"(coef), [bias] "v"(bias) \
+          [mirror] "v"(r.mirror), [stkb] "v"(stkb), [nodes] "s"(nodes), [sfc] "s"(sfc), [coef] "v"(coef), [bias] "v"(bias), \
+          [sact] "s"(sact)                                                                                             \
         : "v48", "v49", "v50", "v51", "v52", "v53", "vcc", "scc", "memory"
 #define VRC_WALK_OPS_LANE [cmpl] "+v"(cmpl)
 #define VRC_WALK_OPS_WAVE [ssteps] "+s"(ssteps), [sb] "=&s"(sb)
@@ -236,7 +240,7 @@ __device__ __forceinline__ uint32_t ray_walk(Ray& r, bool active, const uint2* _
     r.parent_id = pid; r.nd = make_uint2(ndx, ndy);
     r.scale = (int)scale; r.child_offset = co; r.normal = normal;
     if (COUNT_LANE) r.complexity = cmpl;
-    r.kind = kind;
+    r.kind = kind;                              // 0 for a lane without a ray, as ray_setup left it
     r.shift = co ^ r.mirror;                    // child_shift of the child that was hit (unused on a miss)
     return ssteps;
 }
