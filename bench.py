@@ -617,17 +617,12 @@ def main():
         # measured HBM / fabric bytes and instruction-issue numbers of the same workload come from the rocprofv3 PMC
         # passes recorded in profiles/traffic.json -- only when that record was taken on THIS tree's kernel sources
         # (the stage-synchronous kernel has a specialisation for the pinhole camera, see csrc/vrc_kernels.hip launch_render)
-        pinhole = cam.aperture == 0.0 and math.copysign(1.0, cam.aperture) > 0 and 1e-30 <= cam.focal_length < float("inf")
-        # (whole-spp work units select the 8-waves-per-SIMD build of the one-bounce pinhole kernel, vrc_api.cpp render_impl)
-        wide = (pinhole and cfg.get("gi_bounces", 1) <= 1 and whole_spp_units and spp > 1 and depth <= 10
-                and not (args.tuning and 0 < int(args.tuning.split(",")[0]) < 8))
-        sync_kernel_name = (("k_render_sync_pinhole" if pinhole else "k_render_sync") + ("" if cfg.get("gi_bounces", 1) <= 1 else "2")
-                            + ("_resolved" if fused else "") + ("_w8" if wide else ""))
+        sync_kernel_name = rcs[0].lastKernel()       # the build the library chose for this kind of launch (vrc_renderer_last_kernel)
         rec, why = pmc_record(f"{args.config}_n{world}" + ("" if F > 1 else "_inflight1")) if args.kernel == 2 else (None, "PMC record exists for k_render_sync only")
         traffic = rec["traffic_bytes"] if rec else None
         roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
-                "kernel": sync_kernel_name if args.kernel == 2 else {0: "k_render_tile", 1: "k_render"}[args.kernel], "kernel_ms": round(kernel_ms, 4),
+                "kernel": sync_kernel_name, "kernel_ms": round(kernel_ms, 4),
                 "kernel_ms_is": ("events around each launch, averaged (launches do not overlap)" if F == 1 else
                                  f"chip time per launch: HIP events from the first timed launch's start to the last one's end on the {F} "
                                  "launch streams / steps" + (" (includes this rank's resolve / exchange kernels)" if dist_on else "")

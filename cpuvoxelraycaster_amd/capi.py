@@ -103,6 +103,7 @@ SYMBOLS = {
     "vrc_renderer_set_kernel": (_int, [_vp, _u32]),
     "vrc_renderer_set_sample_chunk": (_int, [_vp, _u32]),
     "vrc_renderer_set_invariant_ray_reuse": (_int, [_vp, _u32]),
+    "vrc_renderer_last_kernel": (C.c_char_p, [_vp]),
     "vrc_stream_create": (_int, [_int, C.POINTER(_vp)]),
     "vrc_stream_destroy": (_int, [_int, _vp]),
     "vrc_stream_synchronize": (_int, [_int, _vp]),

@@ -104,6 +104,7 @@ struct vrc_renderer {
     bool queue_zero[2] = {false, false};
     uint32_t* d_tile_done = nullptr;   // one arrival counter per 8 x 8 tile (fused resolve), zero between frames
     Tuning tuning;      // snapshot of the process defaults at creation; vrc_renderer_set_* change it
+    const char* last_kernel = "";   // symbol of the frame kernel the last vrc_render_frame* launched
 };
 
 extern "C" const char* vrc_last_error(void) { return g_err; }
@@ -186,6 +187,7 @@ extern "C" int vrc_renderer_set_invariant_ray_reuse(vrc_renderer* r, uint32_t on
     r->tuning.reuse_invariant = on != 0;
     return VRC_OK;
 }
+extern "C" const char* vrc_renderer_last_kernel(const vrc_renderer* r) { return r ? r->last_kernel : ""; }
 extern "C" int vrc_renderer_set_kernel(vrc_renderer* r, uint32_t kernel)
 {
     if (!r) return fail(VRC_ERR_INVALID, "null renderer");
@@ -604,14 +606,13 @@ int render_impl(vrc_renderer* r, const vrc_camera* cam, const vrc_frame_params* 
     } else if (tuning.kernel == VRC_KERNEL_SYNC) {
         const uint32_t lds = (s->depth - 1) * 2048u + 1536u + 128u;
         const uint32_t fit = 163840u / lds;
-        bpc = vrc::sync_max_blocks_per_cu();          // its own default: as many as registers allow
-        // whole-spp work units (set by a host that keeps frames in flight): the pinhole kernel's 8-waves-per-SIMD build
+        // which build of the kernel (waves per SIMD = workgroups per CU): by the kind of launch, or the caller's choice
         const bool whole_spp = a.p.use_samples && a.p.spp > 1 && tuning.sample_chunk >= a.p.spp;
-        if (whole_spp && a.p.gi_bounces <= 1 && vrc::camera_is_pinhole(a.cam) && vrc::sync_wide_blocks_per_cu() <= fit &&
-            !(tuning.blocks_per_cu_set && tuning.blocks_per_cu < vrc::sync_wide_blocks_per_cu())) {
-            a.wide = 1u;
-            bpc = vrc::sync_wide_blocks_per_cu();
-        }
+        uint32_t waves = vrc::sync_waves_for(vrc::camera_is_pinhole(a.cam), a.p.gi_bounces <= 1, a.p.use_gi != 0, whole_spp,
+                                             (uint64_t)a.n_items * a.p.spp, tuning.blocks_per_cu_set ? tuning.blocks_per_cu : 0u);
+        if (waves > fit) waves = vrc::sync_max_blocks_per_cu();          // deep trees: the stacks of 8 workgroups do not fit a CU's LDS
+        a.waves = waves;
+        bpc = waves;
         if (tuning.blocks_per_cu_set && tuning.blocks_per_cu < bpc) bpc = tuning.blocks_per_cu;
         if (bpc > fit) bpc = fit;
     }
@@ -647,7 +648,7 @@ int render_impl(vrc_renderer* r, const vrc_camera* cam, const vrc_frame_params* 
         want = (units + VRC_RENDER_BLOCK / 64 - 1) / (VRC_RENDER_BLOCK / 64);
     }
     const uint32_t grid = (uint32_t)(want < cap ? want : cap);
-    HIP_TRY(vrc::launch_render(a, grid, (int)tuning.kernel, st));
+    HIP_TRY(vrc::launch_render(a, grid, (int)tuning.kernel, st, &r->last_kernel));
     return VRC_OK;
 }
 }  // namespace

@@ -69,8 +69,8 @@ struct FrameArgs {
     // pinhole kernels (vrc_renderer_set_invariant_ray_reuse): walk a work unit's sample-invariant rays (the primary ray
     // and the shadow ray of its hit) once instead of once per sample; same image, fewer walks executed and counted
     uint32_t reuse_invariant;
-    // host only: launch the 8-waves-per-SIMD build of the pinhole kernel (see sync_wide_blocks_per_cu)
-    uint32_t wide;
+    // host only: which build of the stage-synchronous kernel to launch, by waves per SIMD (6, 7 or 8; see sync_waves_for)
+    uint32_t waves;
     uint32_t* tile_done;
     uint32_t* resolve_dst;
     vrc_camera cam;
@@ -84,14 +84,17 @@ hipError_t launch_grid_cast(const uint8_t* cells, int X, int Y, int Z, uint64_t 
 uint32_t tile_wave_lds_bytes();       // LDS job pool per wave of k_render_tile
 uint32_t tile_max_blocks_per_cu();    // register-limited workgroups per CU of k_render_tile
 uint32_t sync_max_blocks_per_cu();    // ... of k_render_sync
-// k_render_sync_pinhole{,_resolved} also exist compiled for 8 waves per SIMD (64 VGPRs): better latency hiding, a longer
-// ragged end of the launch.  That pays when launches overlap (the next frame's launch covers the end: C3 1.29 -> 1.26 ms, C5
-// 18.98 -> 18.49 ms with three frames in flight) and costs when a launch has the chip to itself (1.40 -> 1.41 ms) or is
-// short (C2 0.087 -> 0.097 ms), so it is used for whole-spp work units -- the unit policy of a host that keeps frames in
-// flight -- and never otherwise.
-uint32_t sync_wide_blocks_per_cu();
+// The one-bounce stage-synchronous kernels exist in several builds by waves per SIMD: 6 (80 VGPRs), and 7 (72; pinhole
+// only) and 8 (64).  More waves hide more latency and make the end of a launch more ragged; which wins depends on the
+// launch (tools/ab_variants.sh, C3 / C4 / C2 frames, ms):
+//   pinhole + GI, one launch at a time (automatic chunk)   6: 1.399   7: 1.360   8: 1.400
+//   pinhole, whole-spp units, three frames in flight       6: 1.253             8: 1.233   (C5: 18.69 / 18.19)
+//   lens (DOF) + GI                                        6: 1.540   7: 1.543   8: 1.522   (one at a time: 1.657 / 1.663 / 1.641)
+//   short launch (C2: 1280 x 720, primary + shadow, 1 spp) 6: 0.080   7: 0.086   8: 0.092
+// sync_waves_for picks by that table; a caller's vrc_renderer_set_tuning(blocks_per_cu) overrides it.
+uint32_t sync_waves_for(bool pinhole, bool one_bounce, bool use_gi, bool whole_spp_units, uint64_t pixel_samples, uint32_t requested);
 bool camera_is_pinhole(const vrc_camera& cam);   // the host's predicate for the pinhole kernels (see launch_render)
-hipError_t launch_render(const FrameArgs& a, uint32_t grid_blocks, int kernel, hipStream_t st);
+hipError_t launch_render(const FrameArgs& a, uint32_t grid_blocks, int kernel, hipStream_t st, const char** launched);
 hipError_t launch_resolve(const void* accum, void* image, uint32_t n, hipStream_t st);
 hipError_t launch_fill_u32(void* p, uint32_t value, uint64_t n, hipStream_t st);
 hipError_t launch_sanitize_nodes(void* nodes, uint64_t n, hipStream_t st);   // leaf_mask &= child_mask

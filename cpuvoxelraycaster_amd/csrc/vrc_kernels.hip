@@ -829,9 +829,6 @@ k_render_tile(const FrameArgs a)
 #ifndef VRC_SYNC_MIN_WAVES
 #define VRC_SYNC_MIN_WAVES 6
 #endif
-#ifndef VRC_SYNC_WIDE_WAVES
-#define VRC_SYNC_WIDE_WAVES 8
-#endif
 
 #ifdef VRC_PROBE
 __device__ __forceinline__ uint32_t probe_wave_max(uint32_t v)
@@ -1333,9 +1330,13 @@ VRC_SYNC_KERNEL(k_render_sync_resolved, false, true, true, VRC_SYNC_MIN_WAVES)
 VRC_SYNC_KERNEL(k_render_sync2_resolved, false, false, true, VRC_SYNC_MIN_WAVES)
 VRC_SYNC_KERNEL(k_render_sync_pinhole_resolved, true, true, true, VRC_SYNC_MIN_WAVES)
 VRC_SYNC_KERNEL(k_render_sync_pinhole2_resolved, true, false, true, VRC_SYNC_MIN_WAVES)
-// the one-bounce pinhole kernels at 8 waves per SIMD, for launches that overlap (vrc_internal.h: sync_wide_blocks_per_cu)
-VRC_SYNC_KERNEL(k_render_sync_pinhole_w8, true, true, false, VRC_SYNC_WIDE_WAVES)
-VRC_SYNC_KERNEL(k_render_sync_pinhole_resolved_w8, true, true, true, VRC_SYNC_WIDE_WAVES)
+// the one-bounce kernels at 7 and 8 waves per SIMD (vrc_internal.h: sync_waves_for)
+VRC_SYNC_KERNEL(k_render_sync_pinhole_w7, true, true, false, 7)
+VRC_SYNC_KERNEL(k_render_sync_pinhole_resolved_w7, true, true, true, 7)
+VRC_SYNC_KERNEL(k_render_sync_pinhole_w8, true, true, false, 8)
+VRC_SYNC_KERNEL(k_render_sync_pinhole_resolved_w8, true, true, true, 8)
+VRC_SYNC_KERNEL(k_render_sync_w8, false, true, false, 8)
+VRC_SYNC_KERNEL(k_render_sync_resolved_w8, false, true, true, 8)
 #undef VRC_SYNC_KERNEL
 
 // ---------------------------------------------------------------------------
@@ -1512,7 +1513,15 @@ hipError_t launch_grid_cast(const uint8_t* cells, int X, int Y, int Z, uint64_t 
 uint32_t tile_wave_lds_bytes() { return TILE_WAVE_LDS; }
 uint32_t tile_max_blocks_per_cu() { return VRC_TILE_MIN_WAVES; }
 uint32_t sync_max_blocks_per_cu() { return VRC_SYNC_MIN_WAVES; }
-uint32_t sync_wide_blocks_per_cu() { return VRC_SYNC_WIDE_WAVES; }
+uint32_t sync_waves_for(bool pinhole, bool one_bounce, bool use_gi, bool whole_spp_units, uint64_t pixel_samples, uint32_t requested)
+{
+    if (!one_bounce) return VRC_SYNC_MIN_WAVES;                        // the 2-bounce extension has the one build
+    if (requested)                                                     // the caller's choice, rounded down to a build that exists
+        return requested >= 8u ? 8u : (requested == 7u && pinhole ? 7u : VRC_SYNC_MIN_WAVES);
+    if (pixel_samples * (use_gi ? 2u : 1u) < (4ull << 20)) return VRC_SYNC_MIN_WAVES;   // short launch
+    if (pinhole) return whole_spp_units ? 8u : (use_gi ? 7u : VRC_SYNC_MIN_WAVES);
+    return use_gi ? 8u : VRC_SYNC_MIN_WAVES;
+}
 
 bool camera_is_pinhole(const vrc_camera& cam)
 {
@@ -1529,27 +1538,38 @@ bool camera_is_pinhole(const vrc_camera& cam)
     return pinhole;
 }
 
-hipError_t launch_render(const FrameArgs& a, uint32_t grid_blocks, int kernel, hipStream_t st)
+hipError_t launch_render(const FrameArgs& a, uint32_t grid_blocks, int kernel, hipStream_t st, const char** launched)
 {
+    const char* name = "";
     if (kernel == VRC_KERNEL_MIXED) {
+        name = "k_render";
         const size_t lds = (size_t)(a.depth - 1) * VRC_RENDER_BLOCK * sizeof(uint2) + 1536;
         hipLaunchKernelGGL(k_render, dim3(grid_blocks), dim3(VRC_RENDER_BLOCK), lds, st, a);
     } else if (kernel == VRC_KERNEL_TILE) {
+        name = "k_render_tile";
         const size_t lds = (size_t)(a.depth - 1) * VRC_RENDER_BLOCK * sizeof(uint2) + 4 * TILE_WAVE_LDS + 1536;
         hipLaunchKernelGGL(k_render_tile, dim3(grid_blocks), dim3(VRC_RENDER_BLOCK), lds, st, a);
     } else {
         const size_t lds = (size_t)(a.depth - 1) * VRC_RENDER_BLOCK * sizeof(uint2) + 1536 + 128;   // + the waves' counters
         const bool pinhole = camera_is_pinhole(a.cam);
         const bool one = a.p.gi_bounces <= 1u, fused = a.fused_resolve != 0u;
-        const bool wide = a.wide != 0u && pinhole && one;
-        void (*kernel_fn)(const FrameArgs) =
-            wide    ? (fused ? k_render_sync_pinhole_resolved_w8 : k_render_sync_pinhole_w8) :
-            pinhole ? (one ? (fused ? k_render_sync_pinhole_resolved : k_render_sync_pinhole)
-                           : (fused ? k_render_sync_pinhole2_resolved : k_render_sync_pinhole2))
-                    : (one ? (fused ? k_render_sync_resolved : k_render_sync)
-                           : (fused ? k_render_sync2_resolved : k_render_sync2));
+        const uint32_t waves = one ? a.waves : 0u;
+        struct Build { void (*fn)(const FrameArgs); const char* name; };
+#define VRC_BUILD(k) Build{k, #k}
+        const Build b =
+            (waves == 8u && pinhole)  ? (fused ? VRC_BUILD(k_render_sync_pinhole_resolved_w8) : VRC_BUILD(k_render_sync_pinhole_w8)) :
+            (waves == 7u && pinhole)  ? (fused ? VRC_BUILD(k_render_sync_pinhole_resolved_w7) : VRC_BUILD(k_render_sync_pinhole_w7)) :
+            (waves == 8u && !pinhole) ? (fused ? VRC_BUILD(k_render_sync_resolved_w8) : VRC_BUILD(k_render_sync_w8)) :
+            pinhole ? (one ? (fused ? VRC_BUILD(k_render_sync_pinhole_resolved) : VRC_BUILD(k_render_sync_pinhole))
+                           : (fused ? VRC_BUILD(k_render_sync_pinhole2_resolved) : VRC_BUILD(k_render_sync_pinhole2)))
+                    : (one ? (fused ? VRC_BUILD(k_render_sync_resolved) : VRC_BUILD(k_render_sync))
+                           : (fused ? VRC_BUILD(k_render_sync2_resolved) : VRC_BUILD(k_render_sync2)));
+#undef VRC_BUILD
+        void (*kernel_fn)(const FrameArgs) = b.fn;
+        name = b.name;
         hipLaunchKernelGGL(kernel_fn, dim3(grid_blocks), dim3(VRC_RENDER_BLOCK), lds, st, a);
     }
+    if (launched) *launched = name;
     return hipGetLastError();
 }
 

@@ -208,6 +208,10 @@ class RayCaster:
     def setSampleChunk(self, samples_per_unit):
         check(capi.load().vrc_renderer_set_sample_chunk(self._h, samples_per_unit))
 
+    def lastKernel(self):
+        """symbol of the frame kernel the last renderFrame* launched (what a rocprofv3 trace of the run lists)"""
+        return capi.load().vrc_renderer_last_kernel(self._h).decode()
+
     def setInvariantRayReuse(self, on=True):
         """beyond the reference: pinhole camera, walk a work unit's primary and shadow ray once instead of once per sample
         (same image; stats then count the walks executed).  include/vrc.h: vrc_renderer_set_invariant_ray_reuse."""
