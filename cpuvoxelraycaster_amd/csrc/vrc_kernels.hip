@@ -1518,8 +1518,9 @@ uint32_t sync_waves_for(bool pinhole, bool one_bounce, bool use_gi, bool whole_s
     if (!one_bounce) return VRC_SYNC_MIN_WAVES;                        // the 2-bounce extension has the one build
     if (requested)                                                     // the caller's choice, rounded down to a build that exists
         return requested >= 8u ? 8u : (requested == 7u && pinhole ? 7u : VRC_SYNC_MIN_WAVES);
+    if (pinhole && whole_spp_units) return 8u;                         // also on an eighth of the frame (tools/shard_inflight.py)
     if (pixel_samples * (use_gi ? 2u : 1u) < (4ull << 20)) return VRC_SYNC_MIN_WAVES;   // short launch
-    if (pinhole) return whole_spp_units ? 8u : (use_gi ? 7u : VRC_SYNC_MIN_WAVES);
+    if (pinhole) return use_gi ? 7u : VRC_SYNC_MIN_WAVES;
     return use_gi ? 8u : VRC_SYNC_MIN_WAVES;
 }
 

@@ -9,6 +9,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # four frame streams + the default stream would share hardware queues
 import torch
 import bench
 import cpuvoxelraycaster_amd as vrc
@@ -18,6 +19,7 @@ depth, W, H, spp = cfg["depth"], cfg["width"], cfg["height"], cfg["spp"]
 svo = vrc.LSVO.fromFastNoiseTerrain(depth, textures=vrc.load_textures())
 cam = vrc.reference_camera(depth, pitch=-0.5)
 L = vrc.capi.load()
+BLOCKS = int(os.environ.get("VRC_BLOCKS", "0"))
 
 
 def period(N, F, whole):
@@ -28,6 +30,8 @@ def period(N, F, whole):
         rc.use_gi, rc.use_samples, rc.shadow_samples = True, True, 1
         if whole:
             rc.setSampleChunk(spp)
+        if BLOCKS:
+            rc.setTuning(blocks_per_cu=BLOCKS)      # force the 6 / 7 / 8 waves-per-SIMD build (A/B of sync_waves_for's choice)
         rcs.append(rc)
     streams = [torch.cuda.Stream() for _ in range(F)]
     bufs = [torch.empty(L.vrc_shard_bytes(W, H, 8, N), dtype=torch.uint8, device="cuda") for _ in range(F)]
