@@ -48,7 +48,7 @@ struct Tuning {
     uint32_t kernel = VRC_KERNEL_SYNC;
     bool blocks_per_cu_set = false;
     uint32_t sample_chunk = 0;   // 0 = automatic
-    uint32_t tail_units_per_wave = 3;   // automatic chunking: units of half the chunk for the last tiles (0 = off)
+    uint32_t tail_units_per_wave = 4;   // automatic chunking: units of half the chunk for the last tiles (0 = off); tools/chunk_time.py
     bool reuse_invariant = false;       // pinhole camera: walk a unit's sample-invariant rays once (never a process default)
 };
 Tuning g_tuning;
@@ -631,7 +631,7 @@ int render_impl(vrc_renderer* r, const vrc_camera* cam, const vrc_frame_params* 
             if (c == 2 && tiles * ((a.p.spp + 1) / 2) < 8 * waves) c = 1;
         }
         a.sample_chunk = c < a.p.spp ? c : 0;
-        // shorter units for the tiles handed out last (about three per wave): halves the spread of the waves' end times
+        // shorter units for the tiles handed out last (about four per wave): halves the spread of the waves' end times
         uint64_t units = tiles * ((a.p.spp + c - 1) / c);
         if (!tuning.sample_chunk && c >= 2 && tuning.tail_units_per_wave) {
             const uint32_t ct = c / 2, cpt_tail = (a.p.spp + ct - 1) / ct;

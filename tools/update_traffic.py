@@ -60,7 +60,8 @@ def main():
     log = os.path.join(src, "stats.log")
     if os.path.exists(log):
         with open(os.path.join(ROOT, dst_prefix + "_stats_bench.json.log"), "w") as f:
-            f.write(open(log).read().strip().splitlines()[-1] + "\n")
+            lines = [ln for ln in open(log).read().splitlines() if ln.startswith("{")]      # the bench line, not rocprofv3's chatter
+            f.write((lines[-1] if lines else "") + "\n")
     path = os.path.join(ROOT, "profiles", "traffic.json")
     doc = json.load(open(path)) if os.path.exists(path) else {}
     if "entries" not in doc:
