@@ -76,6 +76,10 @@ def main():
             # executed, same frame; anything else: no effect at all)
             reuse = bool(rng.integers(0, 4) == 0)
             rc.setInvariantRayReuse(reuse)
+            # the 6 / 7 / 8 waves-per-SIMD builds of the stage-synchronous kernel (0 = the library's choice)
+            blocks = int(rng.choice([0, 0, 6, 7, 8]))
+            if blocks:
+                rc.setTuning(blocks_per_cu=blocks)
             S = float(1 << depth)
             light = vrc.reference_light(depth)
             rc.setLightPosition(light)
@@ -141,7 +145,7 @@ def main():
             rays_total += rr
             if not ok:
                 print("FRAME MISMATCH", it, dict(depth=depth, W=W, H=H, kernel=kernel, spp=spp, gi=rc.use_gi, samples=use_samples,
-                                                 checker=checker, fused=fused, reuse=reuse, shard=(row_block, shard_index, shard_count))); bad += 1
+                                                 checker=checker, fused=fused, reuse=reuse, blocks=blocks, shard=(row_block, shard_index, shard_count))); bad += 1
             vrc.capi.check(L.vrc_set_kernel(2)); vrc.capi.check(L.vrc_set_sample_chunk(0))
     print(f"fuzz: {it} cases ({frames} frames), {rays_total} rays compared, {bad} mismatches, {time.time() - t0:.0f} s")
     sys.exit(1 if bad else 0)
