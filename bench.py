@@ -33,7 +33,6 @@ Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
-import math
 import os
 import sys
 import time

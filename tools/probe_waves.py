@@ -2,9 +2,7 @@
 """Diagnostics: build libvrc_hip with -DVRC_PROBE into gpurun_out/ and print when the waves of one k_render_sync
 launch start and end (tail study).  Usage (GPU box): python tools/probe_waves.py [--config c3]"""
 import argparse
-import ctypes as C
 import os
-import subprocess
 import sys
 
 import numpy as np
