@@ -84,8 +84,8 @@ hipError_t launch_grid_cast(const uint8_t* cells, int X, int Y, int Z, uint64_t 
 uint32_t tile_wave_lds_bytes();       // LDS job pool per wave of k_render_tile
 uint32_t tile_max_blocks_per_cu();    // register-limited workgroups per CU of k_render_tile
 uint32_t sync_max_blocks_per_cu();    // ... of k_render_sync
-// The one-bounce stage-synchronous kernels exist in several builds by waves per SIMD: 6 (80 VGPRs), and 7 (72; pinhole
-// only) and 8 (64).  More waves hide more latency and make the end of a launch more ragged; which wins depends on the
+// The stage-synchronous kernels exist in several builds by waves per SIMD: 6 (80 VGPRs; all of them), 7 (72; one-bounce
+// pinhole) and 8 (64; one-bounce, and the pinhole kernels of the 2-bounce extension: 1.950 -> 1.900 ms).  More waves hide more latency and make the end of a launch more ragged; which wins depends on the
 // launch (tools/ab_variants.sh, C3 / C4 / C2 frames, ms):
 //   pinhole + GI, one launch at a time (automatic chunk)   6: 1.399   7: 1.360   8: 1.400
 //   pinhole, whole-spp units, three frames in flight       6: 1.253             8: 1.233   (C5: 18.69 / 18.19)

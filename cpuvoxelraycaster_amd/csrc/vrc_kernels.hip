@@ -1337,6 +1337,9 @@ VRC_SYNC_KERNEL(k_render_sync_pinhole_w8, true, true, false, 8)
 VRC_SYNC_KERNEL(k_render_sync_pinhole_resolved_w8, true, true, true, 8)
 VRC_SYNC_KERNEL(k_render_sync_w8, false, true, false, 8)
 VRC_SYNC_KERNEL(k_render_sync_resolved_w8, false, true, true, 8)
+// ... and the pinhole kernels of the 2-bounce extension at 8
+VRC_SYNC_KERNEL(k_render_sync_pinhole2_w8, true, false, false, 8)
+VRC_SYNC_KERNEL(k_render_sync_pinhole2_resolved_w8, true, false, true, 8)
 #undef VRC_SYNC_KERNEL
 
 // ---------------------------------------------------------------------------
@@ -1515,9 +1518,10 @@ uint32_t tile_max_blocks_per_cu() { return VRC_TILE_MIN_WAVES; }
 uint32_t sync_max_blocks_per_cu() { return VRC_SYNC_MIN_WAVES; }
 uint32_t sync_waves_for(bool pinhole, bool one_bounce, bool use_gi, bool whole_spp_units, uint64_t pixel_samples, uint32_t requested)
 {
-    if (!one_bounce) return VRC_SYNC_MIN_WAVES;                        // the 2-bounce extension has the one build
+    if (!one_bounce && !pinhole) return VRC_SYNC_MIN_WAVES;            // 2-bounce extension with a lens: the one build
     if (requested)                                                     // the caller's choice, rounded down to a build that exists
-        return requested >= 8u ? 8u : (requested == 7u && pinhole ? 7u : VRC_SYNC_MIN_WAVES);
+        return requested >= 8u ? 8u : (requested == 7u && pinhole && one_bounce ? 7u : VRC_SYNC_MIN_WAVES);
+    if (!one_bounce) return whole_spp_units ? 8u : VRC_SYNC_MIN_WAVES;
     if (pinhole && whole_spp_units) return 8u;                         // also on an eighth of the frame (tools/shard_inflight.py)
     if (pixel_samples * (use_gi ? 2u : 1u) < (4ull << 20)) return VRC_SYNC_MIN_WAVES;   // short launch
     if (pinhole) return use_gi ? 7u : VRC_SYNC_MIN_WAVES;
@@ -1554,13 +1558,14 @@ hipError_t launch_render(const FrameArgs& a, uint32_t grid_blocks, int kernel, h
         const size_t lds = (size_t)(a.depth - 1) * VRC_RENDER_BLOCK * sizeof(uint2) + 1536 + 128;   // + the waves' counters
         const bool pinhole = camera_is_pinhole(a.cam);
         const bool one = a.p.gi_bounces <= 1u, fused = a.fused_resolve != 0u;
-        const uint32_t waves = one ? a.waves : 0u;
+        const uint32_t waves = a.waves;
         struct Build { void (*fn)(const FrameArgs); const char* name; };
 #define VRC_BUILD(k) Build{k, #k}
         const Build b =
-            (waves == 8u && pinhole)  ? (fused ? VRC_BUILD(k_render_sync_pinhole_resolved_w8) : VRC_BUILD(k_render_sync_pinhole_w8)) :
-            (waves == 7u && pinhole)  ? (fused ? VRC_BUILD(k_render_sync_pinhole_resolved_w7) : VRC_BUILD(k_render_sync_pinhole_w7)) :
-            (waves == 8u && !pinhole) ? (fused ? VRC_BUILD(k_render_sync_resolved_w8) : VRC_BUILD(k_render_sync_w8)) :
+            (waves == 8u && pinhole && one)  ? (fused ? VRC_BUILD(k_render_sync_pinhole_resolved_w8) : VRC_BUILD(k_render_sync_pinhole_w8)) :
+            (waves == 8u && pinhole)         ? (fused ? VRC_BUILD(k_render_sync_pinhole2_resolved_w8) : VRC_BUILD(k_render_sync_pinhole2_w8)) :
+            (waves == 7u && pinhole && one)  ? (fused ? VRC_BUILD(k_render_sync_pinhole_resolved_w7) : VRC_BUILD(k_render_sync_pinhole_w7)) :
+            (waves == 8u && one)             ? (fused ? VRC_BUILD(k_render_sync_resolved_w8) : VRC_BUILD(k_render_sync_w8)) :
             pinhole ? (one ? (fused ? VRC_BUILD(k_render_sync_pinhole_resolved) : VRC_BUILD(k_render_sync_pinhole))
                            : (fused ? VRC_BUILD(k_render_sync_pinhole2_resolved) : VRC_BUILD(k_render_sync_pinhole2)))
                     : (one ? (fused ? VRC_BUILD(k_render_sync_resolved) : VRC_BUILD(k_render_sync))

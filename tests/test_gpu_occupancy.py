@@ -17,10 +17,10 @@ def scene(built, heights, textures):
     return nodes, vrc.LSVO(nodes, 7, textures=textures)
 
 
-def make(vrc, svo, depth, W, H, blocks=0, chunk=None, use_gi=True):
+def make(vrc, svo, depth, W, H, blocks=0, chunk=None, use_gi=True, gi_bounces=1):
     rc = vrc.RayCaster(svo, (W, H))
     rc.setLightPosition(vrc.reference_light(depth))
-    rc.use_gi, rc.use_samples, rc.shadow_samples = use_gi, True, 1
+    rc.use_gi, rc.use_samples, rc.shadow_samples, rc.gi_bounces = use_gi, True, 1, gi_bounces
     if chunk is not None:
         rc.setSampleChunk(chunk)
     if blocks:
@@ -69,19 +69,23 @@ def test_library_choice_at_baseline_size(textures):
     svo = vrc.LSVO.fromFastNoiseTerrain(depth, textures=textures)
     pin = vrc.reference_camera(depth, pitch=-0.5)
     dof = vrc.reference_camera(depth, pitch=-0.5, aperture=0.5, focal_length=60.0)
-    cases = [  # camera, whole-spp units, GI, spp, expected kernel
-        (pin, False, True, spp, "k_render_sync_pinhole_w7"),
-        (pin, True, True, spp, "k_render_sync_pinhole_w8"),
-        (pin, True, False, spp, "k_render_sync_pinhole_w8"),
-        (pin, False, False, 1, "k_render_sync_pinhole"),
-        (dof, False, True, spp, "k_render_sync_w8"),
-        (dof, False, False, spp, "k_render_sync"),
+    cases = [  # camera, whole-spp units, GI, spp, bounces, expected kernel
+        (pin, False, True, spp, 1, "k_render_sync_pinhole_w7"),
+        (pin, True, True, spp, 1, "k_render_sync_pinhole_w8"),
+        (pin, True, False, spp, 1, "k_render_sync_pinhole_w8"),
+        (pin, False, False, 1, 1, "k_render_sync_pinhole"),
+        (dof, False, True, spp, 1, "k_render_sync_w8"),
+        (dof, False, False, spp, 1, "k_render_sync"),
+        (pin, True, True, spp, 2, "k_render_sync_pinhole2_w8"),
+        (pin, False, True, spp, 2, "k_render_sync_pinhole2"),
+        (dof, True, True, spp, 2, "k_render_sync2"),
     ]
-    for cam, whole, gi, n, kernel in cases:
-        a = make(vrc, svo, depth, W, H, 0, n if whole else None, gi)
-        b = make(vrc, svo, depth, W, H, 6, n if whole else None, gi)
+    for cam, whole, gi, n, bounces, kernel in cases:
+        a = make(vrc, svo, depth, W, H, 0, n if whole else None, gi, bounces)
+        b = make(vrc, svo, depth, W, H, 6, n if whole else None, gi, bounces)
         a.renderFrame(cam, spp=n); b.renderFrame(cam, spp=n)
-        assert a.lastKernel() == kernel and b.lastKernel() in ("k_render_sync_pinhole", "k_render_sync"), (kernel, a.lastKernel(), b.lastKernel())
+        assert a.lastKernel() == kernel, (kernel, a.lastKernel())
+        assert b.lastKernel() in ("k_render_sync_pinhole", "k_render_sync", "k_render_sync_pinhole2", "k_render_sync2"), b.lastKernel()
         assert np.array_equal(a.readAccum(), b.readAccum()), kernel
         sa, sb = a.stats(), b.stats()
         assert (sa.rays, sa.sum_complexity, sa.primary_hits) == (sb.rays, sb.sum_complexity, sb.primary_hits), kernel
