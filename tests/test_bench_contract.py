@@ -1,0 +1,77 @@
+"""bench.py's output contract, checked on CPU against the bench lines kept under profiles/ (the lines a GPU run of this
+tree printed): one JSON object with the driver's keys, the roofline and cpu_baseline objects with theirs, no baseline
+ratio claimed, a workload-named config, and the consistency relations a reader would check by hand."""
+import json
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.join(ROOT, "profiles", "r02")
+
+DRIVER_KEYS = {"metric": str, "value": (int, float), "unit": str, "n_gpus": int, "steps": int, "warmup": int,
+               "ms_per_step": (int, float), "higher_is_better": bool, "scaling": str, "dtype": str, "data": str, "config": dict}
+
+
+def load(name):
+    with open(os.path.join(R, name)) as f:
+        return json.loads(f.read().strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize("name", ["final_bench.json.log", "final_bench_c2.json.log", "final_bench_c4.json.log", "final_bench_c5.json.log"])
+def test_bench_line_contract(name):
+    d = load(name)
+    for k, t in DRIVER_KEYS.items():
+        assert isinstance(d[k], t), k
+    assert d["vs_baseline"] is None                      # BASELINE.md publishes no number for this metric
+    assert d["higher_is_better"] is True and d["unit"] == "Mrays/s" and d["data"] == "synthetic" and d["n_gpus"] == 1
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    # achieved = algorithmic bytes per launch / kernel time; the kernel cannot take longer than the step it is part of
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) < 0.01 * r["achieved"]
+    assert r["kernel_ms"] <= d["ms_per_step"] * 1.001
+    assert r["achieved"] < r["peak"]
+    # value = rays per frame / frame period
+    assert abs(d["value"] - d["config"]["rays_per_frame"] / (d["ms_per_step"] * 1e-3) / 1e6) < 0.01 * d["value"]
+    # measured traffic is far below the algorithmic bytes (the tree is cache resident) and carries its provenance
+    assert r["traffic"] is not None and r["traffic"] < r["algorithmic_bytes_per_launch"]
+    assert os.path.exists(os.path.join(ROOT, r["traffic_detail"]["profile"]))
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] == "port" and c["unit"] == "Mrays/s" and c["cores"] >= 1
+    kinds = {(v["decomp"].split(" ")[0], v["parity"]) for v in c["variants"]}
+    assert ("4x4x16", True) in kinds and ("omp", True) in kinds and ("omp", False) in kinds
+
+
+def test_rocprof_stats_agree_with_the_bench_lines():
+    """profiles/r02/final_c3*_kernel_stats.csv (rocprofv3 --kernel-trace --stats of the same commands) against the bench
+    lines: one frame in flight, events = rocprof's average; three in flight, rocprof's average = the bracketed figure."""
+    import csv
+
+    def avg_ms(csv_name):
+        with open(os.path.join(R, csv_name)) as f:
+            for row in csv.DictReader(f):
+                if row["Name"].startswith("k_render_sync"):
+                    return row["Name"], float(row["AverageNs"]) / 1e6
+        raise AssertionError(csv_name)
+
+    d = load("final_bench.json.log")
+    name, ms = avg_ms("final_c3_kernel_stats.csv")
+    assert name == d["roofline"]["kernel"]
+    assert abs(ms - d["roofline"]["kernel_ms_bracketed"]) < 0.05 * ms
+    name1, ms1 = avg_ms("final_c3_inflight1_kernel_stats.csv")
+    one = d["extra"]["one_frame_in_flight"]
+    assert abs(ms1 - one["kernel_ms"]) < 0.02 * ms1
+    assert one["kernel_ms"] <= one["ms_per_step"]
+
+
+def test_dist_path_logs_verified_the_gathered_frame():
+    for name in ("force_dist_bench.json.log", "force_dist_root_bench.json.log", "gloo2_bench.json.log"):
+        d = load(name)
+        assert d["config"]["gathered_frame_equals_unsharded"] is True, name
+        assert d["config"]["ranks_in_process_group"] == d["n_gpus"] or name.startswith("force_dist")
