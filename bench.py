@@ -303,9 +303,9 @@ def main():
                                focal_length=(60.0 * (1 << depth) / 512.0 if cfg["aperture"] else 1.0))
     L = vrc.capi.load()
 
-    # `--inflight F` frames in flight per GPU: frame i uses renderer / stream / buffers i % F.  With F = 2 the end of
+    # `--inflight F` frames in flight per GPU: frame i uses renderer / stream / buffers i % F.  With F > 1 the end of
     # one launch (its last work units finish at latency speed with most of the chip idle) overlaps the start of the
-    # next frame's launch, like the all-gather of frame i overlaps the render of frame i + 1.  Frames stay independent
+    # next frames' launches, like the exchange of frame i overlaps the renders after it.  Frames stay independent
     # and complete in order; F = 1 is the plain one-stream loop.
     F = args.inflight if args.inflight > 0 else 3
     # with frames overlapping, a launch's tail is covered by the next frame's launch: work units of ALL the samples of a tile
@@ -332,8 +332,8 @@ def main():
         gathered = [torch.empty(world * shard_bytes, dtype=torch.uint8, device="cuda") for _ in range(2 if F == 1 else F + 2)]
         full = [torch.empty(H * W * 4, dtype=torch.uint8, device="cuda") for _ in range(2 if F == 1 else F + 2)]
     # more slots than frames in flight: a frame's all-gather is only waited for when its slot comes round again, so that
-    # wait does not hold up the frame being issued (with two frames in flight a frame's resolve pass only gets onto the
-    # chip when the next frame's launch starts to drain, and its all-gather runs after that)
+    # wait does not hold up the frame being issued (with frames in flight a frame's exchange only starts when its launch
+    # has drained, i.e. while the following frames' launches run)
     n_slots = 2 if F == 1 else F + 2
 
     ev_pairs = []
