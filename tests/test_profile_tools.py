@@ -1,0 +1,67 @@
+"""The profile tooling behind bench.py's roofline record, on synthetic rocprofv3 output (CPU): tools/pmc_summary.py sums a
+dispatch's rows, reports the median (a launch that carries a neighbour's counts must not move the record), and
+tools/update_traffic.py's unit conversions are the ones MI355X_MICROARCH.md prescribes for gfx950."""
+import csv
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def write_pass(d, name, rows):
+    os.makedirs(os.path.join(d, name, "x"), exist_ok=True)
+    with open(os.path.join(d, name, "x", "1_counter_collection.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Dispatch_Id", "Kernel_Name", "Counter_Name", "Counter_Value"])
+        w.writerows(rows)
+
+
+def test_pmc_summary_median_and_traffic_units(tmp_path):
+    d = str(tmp_path / "roofline_t")
+    k = "k_render_sync_pinhole_resolved_w8"
+    rows = []
+    for disp, scale in ((1, 1.0), (2, 1.0), (3, 2.0), (4, 1.0), (5, 1.0)):     # dispatch 3 carries a neighbour's counts
+        rows += [(disp, k, "FETCH_SIZE", 500.0 * scale), (disp, k, "FETCH_SIZE", 500.0 * scale),   # two rows per dispatch: summed
+                 (disp, "k_resolve_shard", "FETCH_SIZE", 7.0)]
+    write_pass(d, "fetch", rows)
+    write_pass(d, "write", [(i, k, "WRITE_SIZE", 3000.0) for i in range(1, 6)])
+    write_pass(d, "sq1", [(i, k, c, v) for i in range(1, 6) for c, v in (("SQ_INSTS_VALU", 1e9), ("SQ_ACTIVE_INST_VALU", 1e9),
+                                                                       ("SQ_THREAD_CYCLES_VALU", 3.2e10), ("SQ_WAVE_CYCLES", 4e9),
+                                                                       ("SQ_WAIT_INST_ANY", 2e9))])
+    write_pass(d, "grbm", [(i, k, "GRBM_GUI_ACTIVE", 8 * 3.0e6) for i in range(1, 6)])
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), d, "k_render"], text=True)
+    line = [ln.split() for ln in out.splitlines() if ln.startswith("FETCH_SIZE")][0]
+    assert line[1:3] == ["launches", "5"]
+    assert float(line[line.index("median") + 1]) == 1000.0 and float(line[line.index("max") + 1]) == 2000.0
+    assert float(line[line.index("mean") + 1]) == 1200.0
+    # what update_traffic.py makes of it (the arithmetic only; it is not run here because it writes into profiles/)
+    vals = {ln.split()[0]: float(ln.split()[ln.split().index("median") + 1]) for ln in out.splitlines() if "median" in ln}
+    fetch_bytes = 2.0 * vals["FETCH_SIZE"] * 1024.0            # gfx950: FETCH_SIZE counts 128-byte requests as 64 bytes, unit KiB
+    write_bytes = vals["WRITE_SIZE"] * 1024.0
+    assert (fetch_bytes, write_bytes) == (2048000.0, 3072000.0)
+    assert vals["SQ_THREAD_CYCLES_VALU"] / (64.0 * vals["SQ_ACTIVE_INST_VALU"]) == 0.5
+    assert vals["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0 / vals["SQ_INSTS_VALU"] == 3.072
+
+
+def test_traffic_records_are_stamped_and_used_only_for_their_sources(monkeypatch):
+    sys.path.insert(0, ROOT)
+    import bench
+    doc = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    assert doc["entries"]
+    for key, rec in doc["entries"].items():
+        assert len(rec["source_hash"]) == 16 and rec["commit"], key
+        assert abs(rec["traffic_bytes"] - (rec["fetch_bytes"] + rec["write_bytes"])) <= 2, key
+        assert os.path.exists(os.path.join(ROOT, rec["profile"])), key
+    key, rec = next(iter(doc["entries"].items()))
+    # a record is used when the tree's kernel sources + compiler flags hash to its stamp ...
+    monkeypatch.setattr(bench, "kernel_source_hash", lambda: rec["source_hash"])
+    got, why = bench.pmc_record(key)
+    assert got is not None and got["traffic_bytes"] == rec["traffic_bytes"]
+    # ... and refused, with the reason, when they do not, or when there is none for the workload
+    monkeypatch.setattr(bench, "kernel_source_hash", lambda: "0" * 16)
+    got, why = bench.pmc_record(key)
+    assert got is None and why
+    got, why = bench.pmc_record("no_such_workload")
+    assert got is None and why
