@@ -905,6 +905,89 @@ __device__ __forceinline__ float gi_chain(const uint2* __restrict__ nodes, uint2
     return smax(0.0f, acc[0] / 1.0f);
 }
 
+// The 2-bounce extension as straight-line code (the kernels built for it always run exactly two levels: vrc_render_frame
+// rejects gi_bounces > 2, launch_render sends gi_bounces <= 1 to the one-bounce kernels).  Same operations in the same
+// order as gi_chain<false> with gi_bounces = 2 -- level 0 from the primary hit with draws 2, 3, level 1 from the GI hit with
+// draws 4, 5, gi = max(0, acc0 + dot_gi0 * max(0, acc1)) -- without the loop-carried level / draw / base state.
+__device__ __forceinline__ float gi_two_levels(const uint2* __restrict__ nodes, uint2* stk, const uint2 root, const int depth,
+                                               const float n_normalizer, const float lx, const float ly, const float lz,
+                                               const uint32_t seed, const uint32_t fr, const uint32_t pix,
+                                               const float b0px, const float b0py, const float b0pz,
+                                               const float b0nx, const float b0ny, const float b0nz, unsigned long long* ctr)
+{
+    float acc0 = 0.0f, acc1 = 0.0f, dgi0 = 0.0f;
+    Ray r;
+    bool active;
+    float ox, oy, oz, dx, dy, dz;
+    {   // ---- level 0
+        ox = b0px + b0nx * n_normalizer;                                 // :174
+        oy = b0py + b0ny * n_normalizer;
+        oz = b0pz + b0nz * n_normalizer;
+        const float c1 = get_rand(counter_rand(seed, fr, pix, 2u), -1000.0f, 1000.0f);
+        const float c2 = get_rand(counter_rand(seed, fr, pix, 3u), -1000.0f, 1000.0f);
+        float qx = 0.0f, qy = 0.0f, qz = 0.0f;
+        if (b0nx != 0.0f)      { qy = c1; qz = c2; }
+        else if (b0ny != 0.0f) { qx = c1; qz = c2; }
+        else if (b0nz != 0.0f) { qx = c1; qy = c2; }
+        dx = (b0nx + qx) * n_normalizer;                                 // :192
+        dy = (b0ny + qy) * n_normalizer;
+        dz = (b0nz + qz) * n_normalizer;
+        normalize3(dx, dy, dz);
+        dgi0 = dot3(dx, dy, dz, b0nx, b0ny, b0nz);                        // :193
+        active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
+        ray_run_total<VRC_RENDER_BLOCK, 1>(r, active, nodes, stk, depth, 0.5f, 0.0f, ctr);   // :194
+    }
+    Hit g;
+    ray_finish(r, depth, ox, oy, oz, dx, dy, dz, g);
+    if (g.hit) {                                                         // :195-203
+        ox = g.px + g.nx * n_normalizer;
+        oy = g.py + g.ny * n_normalizer;
+        oz = g.pz + g.nz * n_normalizer;
+        dx = lx - ox; dy = ly - oy; dz = lz - oz;
+        normalize3(dx, dy, dz);
+        const float dotl = dot3(g.nx, g.ny, g.nz, dx, dy, dz);             // :200
+        const float contrib = 1000000.0f * smin(0.5f, smax(0.0f, dotl) * dgi0);   // :201
+        active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
+        ray_run_total<VRC_RENDER_BLOCK, 1>(r, active, nodes, stk, depth, 0.5f, 0.0f, ctr);   // :198
+        if (!r.kind) acc0 += contrib;
+        // ---- level 1: the same from the GI hit
+        const float b1nx = g.nx, b1ny = g.ny, b1nz = g.nz;
+        ox = g.px + b1nx * n_normalizer;
+        oy = g.py + b1ny * n_normalizer;
+        oz = g.pz + b1nz * n_normalizer;
+        const float c1 = get_rand(counter_rand(seed, fr, pix, 4u), -1000.0f, 1000.0f);
+        const float c2 = get_rand(counter_rand(seed, fr, pix, 5u), -1000.0f, 1000.0f);
+        float qx = 0.0f, qy = 0.0f, qz = 0.0f;
+        if (b1nx != 0.0f)      { qy = c1; qz = c2; }
+        else if (b1ny != 0.0f) { qx = c1; qz = c2; }
+        else if (b1nz != 0.0f) { qx = c1; qy = c2; }
+        dx = (b1nx + qx) * n_normalizer;
+        dy = (b1ny + qy) * n_normalizer;
+        dz = (b1nz + qz) * n_normalizer;
+        normalize3(dx, dy, dz);
+        const float dgi1 = dot3(dx, dy, dz, b1nx, b1ny, b1nz);
+        active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
+        ray_run_total<VRC_RENDER_BLOCK, 1>(r, active, nodes, stk, depth, 0.5f, 0.0f, ctr);
+        Hit g1;
+        ray_finish(r, depth, ox, oy, oz, dx, dy, dz, g1);
+        if (g1.hit) {
+            ox = g1.px + g1.nx * n_normalizer;
+            oy = g1.py + g1.ny * n_normalizer;
+            oz = g1.pz + g1.nz * n_normalizer;
+            dx = lx - ox; dy = ly - oy; dz = lz - oz;
+            normalize3(dx, dy, dz);
+            const float dotl1 = dot3(g1.nx, g1.ny, g1.nz, dx, dy, dz);
+            const float contrib1 = 1000000.0f * smin(0.5f, smax(0.0f, dotl1) * dgi1);
+            active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
+            ray_run_total<VRC_RENDER_BLOCK, 1>(r, active, nodes, stk, depth, 0.5f, 0.0f, ctr);
+            if (!r.kind) acc1 += contrib1;
+        }
+        acc0 += dgi0 * smax(0.0f, acc1 / 1.0f);                            // :206, innermost level first
+        return smax(0.0f, acc0 / 1.0f);
+    }
+    return smax(0.0f, acc0 / 1.0f);
+}
+
 // sink of one pixel-sample, raycaster.hpp:77-91: sum in registers (sample mode; one accumulator update per unit) or
 // the 0.4 / 0.6 temporal blend into render_image
 __device__ __forceinline__ void sink_sample(const FrameArgs& a, const uint32_t pix, const uint32_t color,
@@ -1126,9 +1209,14 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
                     uint32_t color = 0u;                                             // ColorResult: Black
                     if (hit) {
                         float gi_intensity = 0.0f;
-                        if (a.p.use_gi)
-                            gi_intensity = gi_chain<ONE_BOUNCE>(nodes, stk, root, depth, n_normalizer, lx, ly, lz, gi_bounces, a.p.seed,
+                        if (a.p.use_gi) {
+                            if constexpr (ONE_BOUNCE)
+                                gi_intensity = gi_chain<ONE_BOUNCE>(nodes, stk, root, depth, n_normalizer, lx, ly, lz, gi_bounces, a.p.seed,
                                                     a.p.frame_index + sample, pix, hpx, hpy, hpz, hnx, hny, hnz, ctr);
+                            else
+                                gi_intensity = gi_two_levels(nodes, stk, root, depth, n_normalizer, lx, ly, lz, a.p.seed,
+                                                    a.p.frame_index + sample, pix, hpx, hpy, hpz, hnx, hny, hnz, ctr);
+                        }
                         color = color_mult(albedo, smin(1.0f, smax(0.0f, light_intensity + gi_intensity)));   // :163
                     }
                     sink_sample(a, pix, color, acc_r, acc_g, acc_b);
@@ -1213,9 +1301,14 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
                         }
                         // raycaster.hpp:161,169-207 GI (+ the nested second bounce of the extension)
                         float gi_intensity = 0.0f;
-                        if (a.p.use_gi)
-                            gi_intensity = gi_chain<ONE_BOUNCE>(nodes, stk, root, depth, n_normalizer, lx, ly, lz, gi_bounces, a.p.seed, fr, pix,
+                        if (a.p.use_gi) {
+                            if constexpr (ONE_BOUNCE)
+                                gi_intensity = gi_chain<ONE_BOUNCE>(nodes, stk, root, depth, n_normalizer, lx, ly, lz, gi_bounces, a.p.seed, fr, pix,
                                                     h.px, h.py, h.pz, h.nx, h.ny, h.nz, ctr);
+                            else
+                                gi_intensity = gi_two_levels(nodes, stk, root, depth, n_normalizer, lx, ly, lz, a.p.seed, fr, pix,
+                                                    h.px, h.py, h.pz, h.nx, h.ny, h.nz, ctr);
+                        }
                         color = color_mult(albedo, smin(1.0f, smax(0.0f, light_intensity + gi_intensity)));   // :163
                     }
                     n_pix += 1u;
