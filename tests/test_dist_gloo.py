@@ -7,6 +7,7 @@ import socket
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -67,10 +68,11 @@ def _worker(rank, world, port, W, H, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_sharded_frame_matches_unsharded(built, heights, textures):
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_frame_over_gloo_ranks_matches_unsharded(built, heights, textures, world):
     import oracle_lib as O
     import cpuvoxelraycaster_amd as vrc
-    W, H, world = 200, 100, 2   # 13 row blocks: uneven split, last block partial
+    W, H = 200, 100             # 13 row blocks: uneven split over 2 and over 3 ranks, last block partial
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
