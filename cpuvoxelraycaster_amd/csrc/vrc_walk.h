@@ -62,6 +62,26 @@ namespace vrc {
     "s_andn2_b64 %[sin], %[sin], %[st]\n"                                                       \
     "s_andn2_b64 exec, exec, %[st]\n"
 
+// The x,y pairs of the walk's float arithmetic.  Round 3 (tools/micro/op_issue.hip, op_mix.hip): a v_pk_*_f32 occupies a whole
+// issue slot of the SIMD (~4.7 cycles) and nothing co-issues with it, while a plain v_mul_f32 / v_add_f32 / v_sub_f32 co-issues
+// beside another wave's "slow class" instruction (compare, min3, lshl_or, bfe ...), of which the walk has plenty: two plain
+// operations cost less than the packed one.  -DVRC_WALK_PK restores the packed forms (A/B).
+#ifdef VRC_WALK_PK
+#define VRC_WALK_C_MUL_XY "v_pk_mul_f32 v[48:49], v[38:39], v[32:33]\n"
+#define VRC_WALK_C_SUB_XY "v_pk_add_f32 v[48:49], v[48:49], v[36:37] neg_lo:[0,1] neg_hi:[0,1]\n"
+#define VRC_WALK_H_MUL_XY "v_pk_mul_f32 v[50:51], v[32:33], v[44:45] op_sel_hi:[1,0]\n"
+#define VRC_WALK_H_ADD_XY "v_pk_add_f32 v[50:51], v[50:51], v[48:49]\n"
+#define VRC_WALK_P_SUB_XY "v_pk_add_f32 v[38:39], v[38:39], v[50:51] neg_lo:[0,1] neg_hi:[0,1]\n"
+#define VRC_WALK_P_ADD_XY "v_pk_add_f32 v[48:49], v[38:39], v[50:51]\n"
+#else
+#define VRC_WALK_C_MUL_XY "v_mul_f32_e32 v48, v38, v32\n v_mul_f32_e32 v49, v39, v33\n"
+#define VRC_WALK_C_SUB_XY "v_sub_f32_e32 v48, v48, v36\n v_sub_f32_e32 v49, v49, v37\n"
+#define VRC_WALK_H_MUL_XY "v_mul_f32_e32 v50, v32, v44\n v_mul_f32_e32 v51, v33, v44\n"
+#define VRC_WALK_H_ADD_XY "v_add_f32_e32 v50, v50, v48\n v_add_f32_e32 v51, v51, v49\n"
+#define VRC_WALK_P_SUB_XY "v_sub_f32_e32 v38, v38, v50\n v_sub_f32_e32 v39, v39, v51\n"
+#define VRC_WALK_P_ADD_XY "v_add_f32_e32 v48, v38, v50\n v_add_f32_e32 v49, v39, v51\n"
+#endif
+
 // v32:33 t_coef.xy  v34 t_coef.z  v35 t_offset.z  v36:37 t_offset.xy  v38:39 pos.xy  v40 pos.z
 // v41 t_min  v42:43 {parent_id, t_max} (the stack entry)  v44 scale_f (v45 h)  v46:47 node
 // v48:49 c.xy  v52 c.z  v50:51 / v53 per-axis step / half-point scratch
@@ -78,11 +98,11 @@ namespace vrc {
     "s_add_u32 %[siter], %[siter], 1\n"                                                         \
     COUNTPART                                   /* :73 ++complexity */                          \
     "v_xor_b32_e32 %[cs], %[co], %[mirror]\n"   /* :79 child_shift */                           \
-    "v_pk_mul_f32 v[48:49], v[38:39], v[32:33]\n" /* :76 */                                     \
+    VRC_WALK_C_MUL_XY                           /* :76 */                                       \
     "v_mul_f32_e32 v52, v40, v34\n"                                                             \
     "s_waitcnt vmcnt(0)\n"                      /* node of the current parent */                \
     "v_lshrrev_b32_e32 %[m], %[cs], v46\n"      /* bit 8: child, bit 16: leaf */                \
-    "v_pk_add_f32 v[48:49], v[48:49], v[36:37] neg_lo:[0,1] neg_hi:[0,1]\n"                     \
+    VRC_WALK_C_SUB_XY                                                                           \
     "v_sub_f32_e32 v52, v52, v35\n"                                                             \
     "v_and_b32_e32 %[t], 0x10100, %[m]\n"       /* leaf_mask is a subset of child_mask (k_sanitize_nodes): 0, 0x100 or 0x10100 */ \
     "v_min3_f32 %[tc], v48, v49, v52\n"         /* :77 */                                       \
@@ -109,9 +129,9 @@ namespace vrc {
     "v_lshlrev_b32_e32 %[t], 3, v42\n"                                                          \
     "global_load_dwordx2 v[46:47], %[t], %[nodes]\n"                                            \
     "v_mov_b32_e32 v45, %[tc]\n"                /* :101 */                                      \
-    "v_pk_mul_f32 v[50:51], v[32:33], v[44:45] op_sel_hi:[1,0]\n"   /* :88 half * t_coef + c */ \
+    VRC_WALK_H_MUL_XY                           /* :88 half * t_coef + c */                     \
     "v_mul_f32_e32 v53, v34, v44\n"                                                             \
-    "v_pk_add_f32 v[50:51], v[50:51], v[48:49]\n"                                               \
+    VRC_WALK_H_ADD_XY                                                                           \
     "v_add_f32_e32 v53, v53, v52\n"                                                             \
     TMAXPART                                    /* :110 t_max = tv_max */                       \
     /* :107-109 without masks (anything touching VCC / an SGPR costs ~1.7x a plain VALU op): th > t_min is the \
@@ -143,7 +163,7 @@ namespace vrc {
     "v_cndmask_b32_e64 v51, 0, v44, %[stm]\n"                                                    \
     "v_cndmask_b32_e32 v53, 0, v44, vcc\n"                                                      \
     "v_addc_co_u32_e64 %[normal], %[st], %[normal], %[normal], %[schild]\n"   /* :122 */            \
-    "v_pk_add_f32 v[38:39], v[38:39], v[50:51] neg_lo:[0,1] neg_hi:[0,1]\n"                     \
+    VRC_WALK_P_SUB_XY                                                                           \
     "v_sub_f32_e32 v40, v40, v53\n"                                                             \
     "v_xor_b32_e32 %[co], %[co], %[normal]\n"   /* :121 */                                      \
     "v_and_b32_e32 %[t], %[co], %[normal]\n"                                                    \
@@ -151,7 +171,7 @@ namespace vrc {
     "s_and_b64 exec, exec, vcc\n"                                                               \
     "s_cbranch_execz Lwalk_next%=\n"                                                            \
     /* ---- pop :125-145 ---- */                                                                \
-    "v_pk_add_f32 v[48:49], v[38:39], v[50:51]\n"   /* pos before the step (exact) */           \
+    VRC_WALK_P_ADD_XY                           /* pos before the step (exact) */               \
     "v_add_f32_e32 v52, v40, v53\n"                                                             \
     "v_xor_b32_e32 v48, v48, v38\n"                                                             \
     "v_xor_b32_e32 v49, v49, v39\n"                                                             \
