@@ -9,31 +9,47 @@
 //
 // Same arithmetic, same order, same rounding as ray_step (no FMA, IEEE mul / add / min):
 //   header   c = p * t_coef - t_offset; tc = min3(c); child / span / LOD / leaf tests      (:74-95)
-//   descend  push, h = tc, parent += offset + shift, half, child select, t_max = min(t_max, tc)  (:96-111)
+//   descend  push, parent += offset + shift, half, child select, t_max = min(t_max, tc)    (:96-111)
 //   advance  step mask, p -= step, t_min = tc, child ^= mask                                (:113-122)
-//   pop      differing bits -> scale, stack read, p &= ~0 << scale, child bits, h = 0      (:124-145)
+//   pop      differing bits -> scale, stack read, p &= ~0 << scale, child bits              (:124-145)
 // Exits: LOD cut (kind 2), leaf (kind 1), root left (miss), iteration cap (miss).
 //
-// Register plan: 64-bit pairs are needed for v_pk_mul_f32 / v_pk_add_f32, ds_read_b64 / ds_write_b64
-// and the node load, and inline asm cannot name the halves of a 64-bit operand, so the paired values
-// live in fixed registers v32..v53; everything else is allocated by the compiler.
+// What an instruction costs here (round 3, tools/micro/op_issue.hip, gen_op_mix.py; profiles/r03/op_*.txt).  A SIMD issues in
+// slots of ~4.4-5.5 cycles, filled from DIFFERENT waves with either
+//   two "simple" instructions       v_add/sub/mul/fma_f32, v_mov (class A); v_xor/and/or, v_add/sub_u32, v_lshrrev, v_ashrrev
+//                                   (class B); simple ops with an SGPR operand: v_cndmask, v_addc (class S, not two of them),
+//   one "slow" instruction + one A  every compare, v_min/max, v_min3, v_lshlrev (!), v_lshl_or / lshl_add / add3 / or3 / and_or /
+//                                   bfe, v_ffbh, v_cvt: ~4.4 cycles alone, and nothing but a class-A instruction runs beside it,
+//   or one packed / 24-bit-multiply / lane-access instruction (v_pk_*_f32, v_mul_u32_u24, v_readlane): nothing beside it.
+// So: no packed math (two plain operations co-issue, a packed one does not: C3 frame 1.239 -> 1.136 ms), as few slow-class
+// instructions as the algorithm allows (one slot each), float adds rather than shift-ors where the reference itself adds
+// (pos += scale_f, :107-109), class-A instructions up to the number of slow ones are nearly free.  The scalar unit is the
+// second resource (one per CU, ~1 instruction per cycle for four SIMDs): compares write EXEC directly (v_cmpx) instead of an
+// SGPR pair and an s_and.
+//
+// Register plan: ds_read_b64 / ds_write_b64 move the stack entry {parent_id, t_max} as one register pair and the node load
+// returns a pair; inline asm cannot name the halves of a 64-bit operand, so those four live in fixed registers (v42:43,
+// v46:47); everything else is allocated by the compiler.  Every read-write operand is early-clobber ("+&v"): without it the
+// compiler may give an INPUT that happens to hold the same value (coef = 0.5 and the initial scale_f = 0.5) the same register,
+// and the loop then changes the input under its own feet.
 #pragma once
 
 namespace vrc {
 
-// The span test of :81 / :89, t_min <= min(t_max, tc) (no NaN in the walk).  Without a LOD test one min and one
-// compare (a compare costs 1.7x a min); with it `t_min <= t_max` is needed on its own (:81 guards :82), so two compares.
-#define VRC_WALK_SPAN_MIN                                                                       \
-    "v_min_f32_e32 %[t2], v43, %[tc]\n"         /* :86 tv_max */                                \
-    "v_cmp_le_f32_e32 vcc, v41, %[t2]\n"                                                        \
-    "s_and_b64 %[sin], %[schild], vcc\n"
-#define VRC_WALK_TMAX_MIN "v_mov_b32_e32 v43, %[t2]\n"
-#define VRC_WALK_SPAN_CMP                                                                       \
-    "v_cmp_le_f32_e32 vcc, v41, v43\n"          /* :81 t_min <= t_max */                        \
-    "s_and_b64 %[stm], %[schild], vcc\n"                                                        \
-    "v_cmp_le_f32_e32 vcc, v41, %[tc]\n"        /* with the line above: t_min <= min(t_max, tc), :86,:89 */ \
-    "s_and_b64 %[sin], %[stm], vcc\n"
-#define VRC_WALK_TMAX_CMP "v_min_f32_e32 v43, v43, %[tc]\n"
+typedef uint32_t walk_rsrc_t __attribute__((ext_vector_type(4)));
+
+// Buffer resource over the node array with stride 8 (one LNode): `buffer_load_dwordx2 ... idxen` then takes the node
+// INDEX and the address arithmetic (index * 8) is done by the memory pipeline instead of a slow-class v_lshlrev_b32.
+__device__ __forceinline__ walk_rsrc_t walk_node_rsrc(const uint2* __restrict__ nodes)
+{
+    const uint64_t p = (uint64_t)(uintptr_t)nodes;
+    walk_rsrc_t r;
+    r.x = (uint32_t)p;
+    r.y = ((uint32_t)(p >> 32) & 0xffffu) | (8u << 16);     // base[47:32] | stride 8
+    r.z = 0x20000000u;                                      // records (VRC_MAX_NODES = 2^29)
+    r.w = 0x00020000u;                                      // untyped 32-bit data
+    return r;
+}
 
 // HitPoint::complexity (:73).  Per lane (the per-ray operator returns it, the primary-hit capture records it) or, for the
 // frame kernels, which only need the launch's total: the lanes at the loop top counted by the scalar unit (a lane's
@@ -43,163 +59,149 @@ namespace vrc {
     "s_bcnt1_i32_b64 %[sb], exec\n"                                                             \
     "s_add_u32 %[ssteps], %[ssteps], %[sb]\n"
 
-// LOD_MODE: 0 = no LOD test (coef == bias == 0), 1 = bias == 0 (x + 0 does not change the comparison),
-// 2 = general.
-#define VRC_WALK_LOD_NONE ""
-#define VRC_WALK_LOD_COEF                                                                       \
+// The tests of :81-89 that leave EXEC = the lanes whose child exists and whose span is not empty (LOD cuts taken out).
+// Without a LOD test: t_min <= min(t_max, tc) in one min and one compare (:81 is implied, see ray_step).
+#define VRC_WALK_SPAN_NOLOD                                                                     \
+    "v_cmpx_ne_u32_e32 vcc, 0, %[t]\n"          /* :81 child exists */                          \
+    "v_min_f32_e32 %[t2], v43, %[tc]\n"         /* :86 tv_max */                                \
+    "v_cmpx_le_f32_e32 vcc, %[tmin], %[t2]\n"   /* :81,:89 */
+#define VRC_WALK_TMAX_NOLOD "v_mov_b32_e32 v43, %[t2]\n"
+// With it (LOD_MODE 1: bias == 0, x + 0 does not change the comparison; 2: general): :81 guards :82, so t_min <= t_max is
+// a compare of its own; with it, t_min <= tc is :89.
+#define VRC_WALK_SPAN_LOD(BIASPART)                                                             \
+    "v_cmpx_ne_u32_e32 vcc, 0, %[t]\n"          /* :81 child exists */                          \
+    "v_cmpx_le_f32_e32 vcc, %[tmin], v43\n"     /* :81 t_min <= t_max */                        \
     "v_mul_f32_e32 %[t2], %[coef], %[tc]\n"                                                     \
-    "v_cmp_ge_f32_e32 vcc, %[t2], v44\n"                                                         \
-    "s_and_b64 %[st], %[stm], vcc\n"            /* child && t_min <= t_max && tc*coef >= scale_f */ \
-    "s_or_b64 %[slod], %[slod], %[st]\n"                                                        \
-    "s_andn2_b64 %[sin], %[sin], %[st]\n"                                                       \
-    "s_andn2_b64 exec, exec, %[st]\n"
-#define VRC_WALK_LOD_FULL                                                                       \
-    "v_mul_f32_e32 %[t2], %[coef], %[tc]\n"                                                     \
-    "v_add_f32_e32 %[t2], %[t2], %[bias]\n"                                                     \
-    "v_cmp_ge_f32_e32 vcc, %[t2], v44\n"                                                         \
-    "s_and_b64 %[st], %[stm], vcc\n"                                                            \
-    "s_or_b64 %[slod], %[slod], %[st]\n"                                                        \
-    "s_andn2_b64 %[sin], %[sin], %[st]\n"                                                       \
-    "s_andn2_b64 exec, exec, %[st]\n"
+    BIASPART                                                                                    \
+    "v_cmp_ge_f32_e32 vcc, %[t2], %[sf]\n"      /* :82 tc * coef + bias >= scale_f */           \
+    "s_or_b64 %[slod], %[slod], vcc\n"                                                          \
+    "s_andn2_b64 %[srun], %[srun], vcc\n"                                                       \
+    "s_andn2_b64 exec, exec, vcc\n"                                                             \
+    "v_cmpx_le_f32_e32 vcc, %[tmin], %[tc]\n"   /* :89 */
+#define VRC_WALK_BIAS_NONE ""
+#define VRC_WALK_BIAS_ADD "v_add_f32_e32 %[t2], %[t2], %[bias]\n"
+#define VRC_WALK_TMAX_LOD "v_min_f32_e32 v43, v43, %[tc]\n"
 
-// The x,y pairs of the walk's float arithmetic.  Round 3 (tools/micro/op_issue.hip, op_mix.hip): a v_pk_*_f32 occupies a whole
-// issue slot of the SIMD (~4.7 cycles) and nothing co-issues with it, while a plain v_mul_f32 / v_add_f32 / v_sub_f32 co-issues
-// beside another wave's "slow class" instruction (compare, min3, lshl_or, bfe ...), of which the walk has plenty: two plain
-// operations cost less than the packed one.  -DVRC_WALK_PK restores the packed forms (A/B).
-#ifdef VRC_WALK_PK
-#define VRC_WALK_C_MUL_XY "v_pk_mul_f32 v[48:49], v[38:39], v[32:33]\n"
-#define VRC_WALK_C_SUB_XY "v_pk_add_f32 v[48:49], v[48:49], v[36:37] neg_lo:[0,1] neg_hi:[0,1]\n"
-#define VRC_WALK_H_MUL_XY "v_pk_mul_f32 v[50:51], v[32:33], v[44:45] op_sel_hi:[1,0]\n"
-#define VRC_WALK_H_ADD_XY "v_pk_add_f32 v[50:51], v[50:51], v[48:49]\n"
-#define VRC_WALK_P_SUB_XY "v_pk_add_f32 v[38:39], v[38:39], v[50:51] neg_lo:[0,1] neg_hi:[0,1]\n"
-#define VRC_WALK_P_ADD_XY "v_pk_add_f32 v[48:49], v[38:39], v[50:51]\n"
+#ifdef VRC_WALK_GLOBAL_LOAD   /* A/B: the byte offset computed by the VALU */
+#define VRC_WALK_LOAD_NODE "v_lshlrev_b32_e32 %[m], 3, v42\n global_load_dwordx2 v[46:47], %[m], %[nodes]\n"
 #else
-#define VRC_WALK_C_MUL_XY "v_mul_f32_e32 v48, v38, v32\n v_mul_f32_e32 v49, v39, v33\n"
-#define VRC_WALK_C_SUB_XY "v_sub_f32_e32 v48, v48, v36\n v_sub_f32_e32 v49, v49, v37\n"
-#define VRC_WALK_H_MUL_XY "v_mul_f32_e32 v50, v32, v44\n v_mul_f32_e32 v51, v33, v44\n"
-#define VRC_WALK_H_ADD_XY "v_add_f32_e32 v50, v50, v48\n v_add_f32_e32 v51, v51, v49\n"
-#define VRC_WALK_P_SUB_XY "v_sub_f32_e32 v38, v38, v50\n v_sub_f32_e32 v39, v39, v51\n"
-#define VRC_WALK_P_ADD_XY "v_add_f32_e32 v48, v38, v50\n v_add_f32_e32 v49, v39, v51\n"
+#define VRC_WALK_LOAD_NODE "buffer_load_dwordx2 v[46:47], v42, %[rsrc], 0 idxen\n"
 #endif
 
-// v32:33 t_coef.xy  v34 t_coef.z  v35 t_offset.z  v36:37 t_offset.xy  v38:39 pos.xy  v40 pos.z
-// v41 t_min  v42:43 {parent_id, t_max} (the stack entry)  v44 scale_f (v45 h)  v46:47 node
-// v48:49 c.xy  v52 c.z  v50:51 / v53 per-axis step / half-point scratch
-#define VRC_WALK_ASM(SPANPART, LODPART, TMAXPART, COUNTPART)                                                                \
+// v42:43 {parent_id, t_max} (the stack entry)   v46:47 node
+#define VRC_WALK_ASM(SPANPART, TMAXPART, COUNTPART)                                             \
     "s_mov_b64 %[sentry], exec\n"                                                               \
     "s_and_b64 exec, exec, %[sact]\n"           /* the lanes with a ray to walk */              \
     "s_mov_b64 %[sleaf], 0\n"                                                                   \
     "s_mov_b64 %[slod], 0\n"                                                                    \
-    "s_mov_b32 %[siter], 0\n"                                                                   \
+    "s_mov_b32 %[siter], 0xfffeffff\n"          /* carries out at the 65537th loop top: MAX_ITERATIONS */ \
+    "s_mov_b64 %[srun], exec\n"                                                                 \
     "s_cbranch_execz Lwalk_done%=\n"                                                            \
     "Lwalk_loop%=:\n"                                                                           \
-    "s_cmpk_gt_u32 %[siter], 0xffff\n"          /* safety net, MAX_ITERATIONS */                \
-    "s_cbranch_scc1 Lwalk_done%=\n"                                                             \
     "s_add_u32 %[siter], %[siter], 1\n"                                                         \
+    "s_cbranch_scc1 Lwalk_done%=\n"             /* safety net */                                \
     COUNTPART                                   /* :73 ++complexity */                          \
     "v_xor_b32_e32 %[cs], %[co], %[mirror]\n"   /* :79 child_shift */                           \
-    VRC_WALK_C_MUL_XY                           /* :76 */                                       \
-    "v_mul_f32_e32 v52, v40, v34\n"                                                             \
+    "v_mul_f32_e32 %[cx], %[px], %[tcx]\n"      /* :76 */                                       \
+    "v_mul_f32_e32 %[cy], %[py], %[tcy]\n"                                                      \
+    "v_mul_f32_e32 %[cz], %[pz], %[tcz]\n"                                                      \
     "s_waitcnt vmcnt(0)\n"                      /* node of the current parent */                \
     "v_lshrrev_b32_e32 %[m], %[cs], v46\n"      /* bit 8: child, bit 16: leaf */                \
-    VRC_WALK_C_SUB_XY                                                                           \
-    "v_sub_f32_e32 v52, v52, v35\n"                                                             \
+    "v_sub_f32_e32 %[cx], %[cx], %[tox]\n"                                                      \
+    "v_sub_f32_e32 %[cy], %[cy], %[toy]\n"                                                      \
+    "v_sub_f32_e32 %[cz], %[cz], %[toz]\n"                                                      \
     "v_and_b32_e32 %[t], 0x10100, %[m]\n"       /* leaf_mask is a subset of child_mask (k_sanitize_nodes): 0, 0x100 or 0x10100 */ \
-    "v_min3_f32 %[tc], v48, v49, v52\n"         /* :77 */                                       \
-    "v_cmp_ne_u32_e64 %[schild], 0, %[t]\n"                                                     \
+    "v_min3_f32 %[tc], %[cx], %[cy], %[cz]\n"   /* :77 */                                       \
     SPANPART                                                                                    \
-    LODPART                                                                                     \
-    "v_cmp_lt_u32_e32 vcc, 0x100, %[t]\n"       /* child and leaf */                            \
-    "s_and_b64 %[st], %[sin], vcc\n"            /* leaf hit :90-94 */                           \
-    "s_or_b64 %[sleaf], %[sleaf], %[st]\n"                                                      \
-    "s_andn2_b64 %[sin], %[sin], %[st]\n"       /* lanes that descend */                        \
-    "s_andn2_b64 exec, exec, %[st]\n"                                                           \
-    "s_cbranch_execz Lwalk_done%=\n"                                                            \
-    "s_mov_b64 %[srun], exec\n"                                                                 \
+    "v_cmp_lt_u32_e32 vcc, 0x100, %[t]\n"       /* child and leaf, among the lanes inside: leaf hit :90-94 */ \
+    "s_or_b64 %[sleaf], %[sleaf], vcc\n"                                                        \
+    "s_andn2_b64 %[srun], %[srun], vcc\n"                                                       \
+    "s_cbranch_scc0 Lwalk_done%=\n"             /* nobody left */                               \
+    "s_andn2_b64 exec, exec, vcc\n"             /* lanes that descend */                        \
+    "s_mov_b64 %[sin], exec\n"                                                                  \
+    "s_cbranch_scc0 Lwalk_adv%=\n"                                                              \
     /* ---- descend :96-111 ---- */                                                             \
-    "s_and_b64 exec, %[srun], %[sin]\n"                                                         \
-    "s_cbranch_execz Lwalk_adv%=\n"                                                             \
-    "v_cmp_lt_f32_e32 vcc, %[tc], v45\n"        /* :97 tc_max < h */                            \
-    "v_mul_f32_e32 v44, 0.5, v44\n"             /* :87 half, becomes scale_f :105 */            \
-    "s_and_saveexec_b64 %[st], vcc\n"                                                           \
-    "v_lshl_add_u32 %[t], %[scale], 11, %[stkb]\n"                                              \
-    "ds_write_b64 %[t], v[42:43]\n"             /* :98-99 */                                    \
-    "s_mov_b64 exec, %[st]\n"                                                                   \
+    /* :97-100 the push is unconditional: `tc_max < h` only skips writes of what the slot already holds (the level's    \
+       {parent, t_max} do not change while the walk is below it) or of entries that are never read (last child on the   \
+       ray); h is not kept at all */                                                            \
+    "ds_write_b64 %[sp], v[42:43]\n"                                                            \
+    "v_mul_f32_e32 %[sf], 0.5, %[sf]\n"         /* :87 half, becomes scale_f :105 */            \
     "v_add3_u32 v42, v42, v47, %[cs]\n"         /* :103 */                                      \
-    "v_lshlrev_b32_e32 %[t], 3, v42\n"                                                          \
-    "global_load_dwordx2 v[46:47], %[t], %[nodes]\n"                                            \
-    "v_mov_b32_e32 v45, %[tc]\n"                /* :101 */                                      \
-    VRC_WALK_H_MUL_XY                           /* :88 half * t_coef + c */                     \
-    "v_mul_f32_e32 v53, v34, v44\n"                                                             \
-    VRC_WALK_H_ADD_XY                                                                           \
-    "v_add_f32_e32 v53, v53, v52\n"                                                             \
+    VRC_WALK_LOAD_NODE                                                                          \
+    "v_mul_f32_e32 %[hx], %[tcx], %[sf]\n"      /* :88 half * t_coef + c */                     \
+    "v_mul_f32_e32 %[hy], %[tcy], %[sf]\n"                                                      \
+    "v_mul_f32_e32 %[hz], %[tcz], %[sf]\n"                                                      \
+    "v_add_f32_e32 %[hx], %[hx], %[cx]\n"                                                       \
+    "v_add_f32_e32 %[hy], %[hy], %[cy]\n"                                                       \
+    "v_add_f32_e32 %[hz], %[hz], %[cz]\n"                                                       \
     TMAXPART                                    /* :110 t_max = tv_max */                       \
-    /* :107-109 without masks (anything touching VCC / an SGPR costs ~1.7x a plain VALU op): th > t_min is the \
-       sign of t_min - th (never -0: t_min >= +0; never NaN: both finite), and pos + half sets bit scale-1 of   \
-       the mantissa, which is 0 before (pos is a multiple of 2 * half in [1, 2)) */                          \
-    "v_sub_f32_e32 v50, v41, v50\n"                                                             \
-    "v_sub_f32_e32 v51, v41, v51\n"                                                             \
-    "v_sub_f32_e32 v53, v41, v53\n"                                                             \
-    "v_add_u32_e32 %[scale], -1, %[scale]\n"    /* :104 */                                      \
-    "v_lshrrev_b32_e32 v50, 31, v50\n"                                                          \
-    "v_lshrrev_b32_e32 v51, 31, v51\n"                                                          \
-    "v_lshrrev_b32_e32 v53, 31, v53\n"                                                          \
-    "v_lshl_or_b32 v38, v50, %[scale], v38\n"                                                   \
-    "v_lshl_or_b32 v39, v51, %[scale], v39\n"                                                   \
-    "v_lshl_or_b32 v40, v53, %[scale], v40\n"                                                   \
-    "v_lshl_or_b32 %[co], v51, 1, v50\n"                                                        \
-    "v_lshl_or_b32 %[co], v53, 2, %[co]\n"                                                      \
+    /* :107-109 without compares: th > t_min is the sign of t_min - th (never -0: t_min >= +0; never NaN: both finite); \
+       as a mask it selects scale_f for the float add the reference does, and the child bit */                       \
+    "v_sub_f32_e32 %[hx], %[tmin], %[hx]\n"                                                     \
+    "v_sub_f32_e32 %[hy], %[tmin], %[hy]\n"                                                     \
+    "v_sub_f32_e32 %[hz], %[tmin], %[hz]\n"                                                     \
+    "v_add_u32_e32 %[sp], 0xfffff800, %[sp]\n"  /* :104 --scale: the next stack row down */     \
+    "v_ashrrev_i32_e32 %[hx], 31, %[hx]\n"                                                      \
+    "v_ashrrev_i32_e32 %[hy], 31, %[hy]\n"                                                      \
+    "v_ashrrev_i32_e32 %[hz], 31, %[hz]\n"                                                      \
+    "v_and_b32_e32 %[t], %[sf], %[hx]\n"                                                        \
+    "v_and_b32_e32 %[t2], %[sf], %[hy]\n"                                                       \
+    "v_and_b32_e32 %[m], %[sf], %[hz]\n"                                                        \
+    "v_add_f32_e32 %[px], %[px], %[t]\n"        /* exact: pos is a multiple of 2 * half */      \
+    "v_add_f32_e32 %[py], %[py], %[t2]\n"                                                       \
+    "v_add_f32_e32 %[pz], %[pz], %[m]\n"                                                        \
+    "v_and_b32_e32 %[co], 1, %[hx]\n"                                                           \
+    "v_and_or_b32 %[co], %[hy], 2, %[co]\n"                                                     \
+    "v_and_or_b32 %[co], %[hz], 4, %[co]\n"                                                     \
     /* ---- advance :113-122 ---- */                                                            \
     "Lwalk_adv%=:\n"                                                                            \
     "s_andn2_b64 exec, %[srun], %[sin]\n"                                                       \
-    "s_cbranch_execz Lwalk_next%=\n"                                                            \
-    "v_cmp_le_f32_e64 %[schild], v48, %[tc]\n"      /* :115-118 */                                  \
-    "v_cmp_le_f32_e64 %[stm], v49, %[tc]\n"                                                      \
-    "v_cmp_le_f32_e32 vcc, v52, %[tc]\n"                                                        \
-    "v_mov_b32_e32 v41, %[tc]\n"                /* :120 */                                      \
+    "s_cbranch_scc0 Lwalk_next%=\n"                                                             \
+    "v_cmp_le_f32_e64 %[sx], %[cx], %[tc]\n"    /* :115-118 */                                  \
+    "v_cmp_le_f32_e64 %[sy], %[cy], %[tc]\n"                                                    \
+    "v_cmp_le_f32_e32 vcc, %[cz], %[tc]\n"                                                      \
+    "v_mov_b32_e32 %[tmin], %[tc]\n"            /* :120 */                                      \
     "v_cndmask_b32_e64 %[normal], 0, 1, vcc\n"                                                  \
-    "v_cndmask_b32_e64 v50, 0, v44, %[schild]\n"                                                    \
-    "v_addc_co_u32_e64 %[normal], %[st], %[normal], %[normal], %[stm]\n"                         \
-    "v_cndmask_b32_e64 v51, 0, v44, %[stm]\n"                                                    \
-    "v_cndmask_b32_e32 v53, 0, v44, vcc\n"                                                      \
-    "v_addc_co_u32_e64 %[normal], %[st], %[normal], %[normal], %[schild]\n"   /* :122 */            \
-    VRC_WALK_P_SUB_XY                                                                           \
-    "v_sub_f32_e32 v40, v40, v53\n"                                                             \
+    "v_cndmask_b32_e64 %[hx], 0, %[sf], %[sx]\n"                                                \
+    "v_addc_co_u32_e64 %[normal], %[st], %[normal], %[normal], %[sy]\n"                         \
+    "v_cndmask_b32_e64 %[hy], 0, %[sf], %[sy]\n"                                                \
+    "v_cndmask_b32_e32 %[hz], 0, %[sf], vcc\n"                                                  \
+    "v_addc_co_u32_e64 %[normal], %[st], %[normal], %[normal], %[sx]\n"   /* :122 */            \
+    "v_sub_f32_e32 %[px], %[px], %[hx]\n"                                                       \
+    "v_sub_f32_e32 %[py], %[py], %[hy]\n"                                                       \
+    "v_sub_f32_e32 %[pz], %[pz], %[hz]\n"                                                       \
     "v_xor_b32_e32 %[co], %[co], %[normal]\n"   /* :121 */                                      \
     "v_and_b32_e32 %[t], %[co], %[normal]\n"                                                    \
-    "v_cmp_ne_u32_e32 vcc, 0, %[t]\n"           /* :124 */                                      \
-    "s_and_b64 exec, exec, vcc\n"                                                               \
+    "v_cmpx_ne_u32_e32 vcc, 0, %[t]\n"          /* :124 */                                      \
     "s_cbranch_execz Lwalk_next%=\n"                                                            \
     /* ---- pop :125-145 ---- */                                                                \
-    VRC_WALK_P_ADD_XY                           /* pos before the step (exact) */               \
-    "v_add_f32_e32 v52, v40, v53\n"                                                             \
-    "v_xor_b32_e32 v48, v48, v38\n"                                                             \
-    "v_xor_b32_e32 v49, v49, v39\n"                                                             \
-    "v_xor_b32_e32 v52, v52, v40\n"                                                             \
-    "v_or3_b32 %[t], v48, v49, v52\n"           /* differing_bits :125-131 */                   \
+    "v_add_f32_e32 %[cx], %[px], %[hx]\n"       /* pos before the step (exact) */               \
+    "v_add_f32_e32 %[cy], %[py], %[hy]\n"                                                       \
+    "v_add_f32_e32 %[cz], %[pz], %[hz]\n"                                                       \
+    "v_xor_b32_e32 %[cx], %[cx], %[px]\n"                                                       \
+    "v_xor_b32_e32 %[cy], %[cy], %[py]\n"                                                       \
+    "v_xor_b32_e32 %[cz], %[cz], %[pz]\n"                                                       \
+    "v_or3_b32 %[t], %[cx], %[cy], %[cz]\n"     /* differing_bits :125-131 */                   \
     "v_ffbh_u32_e32 %[t], %[t]\n"                                                               \
-    "v_sub_u32_e32 %[scale], 31, %[t]\n"        /* :132; 0 bits -> 32 -> leaves below */        \
-    "v_cmp_gt_u32_e32 vcc, 23, %[scale]\n"                                                      \
-    "s_andn2_b64 %[st], exec, vcc\n"            /* left the root: miss */                       \
-    "s_andn2_b64 %[srun], %[srun], %[st]\n"                                                     \
-    "s_and_b64 exec, exec, vcc\n"                                                               \
-    "s_cbranch_execz Lwalk_next%=\n"                                                            \
-    "v_lshl_add_u32 %[t], %[scale], 11, %[stkb]\n"                                              \
-    "ds_read_b64 v[42:43], %[t]\n"              /* :134-136 */                                  \
-    "v_lshl_add_u32 v44, %[scale], 23, %[sfc]\n"    /* :133 2^(scale-23) */                     \
-    "v_lshlrev_b32_e64 %[t2], %[scale], -1\n"                                                   \
-    "v_bfe_u32 v48, v38, %[scale], 1\n"         /* :137-143 */                                  \
-    "v_bfe_u32 v49, v39, %[scale], 1\n"                                                         \
-    "v_bfe_u32 v52, v40, %[scale], 1\n"                                                         \
-    "v_and_b32_e32 v38, v38, %[t2]\n"                                                           \
-    "v_and_b32_e32 v39, v39, %[t2]\n"                                                           \
-    "v_and_b32_e32 v40, v40, %[t2]\n"                                                           \
-    "v_lshl_or_b32 %[co], v49, 1, v48\n"                                                        \
-    "v_mov_b32_e32 v45, 0\n"                    /* :144 */                                      \
-    "v_lshl_or_b32 %[co], v52, 2, %[co]\n"                                                      \
+    "v_sub_u32_e32 %[t], 31, %[t]\n"            /* :132 scale; 0 bits -> 32 -> leaves below */  \
+    "v_cmp_le_u32_e32 vcc, 23, %[t]\n"          /* left the root: miss */                       \
+    "s_andn2_b64 %[srun], %[srun], vcc\n"                                                       \
+    "s_andn2_b64 exec, exec, vcc\n"                                                             \
+    "s_cbranch_scc0 Lwalk_next%=\n"                                                             \
+    "v_lshl_add_u32 %[sp], %[t], 11, %[stkb]\n"                                                 \
+    "ds_read_b64 v[42:43], %[sp]\n"             /* :134-136 */                                  \
+    "v_lshl_add_u32 %[sf], %[t], 23, %[sfc]\n"  /* :133 2^(scale-23) */                         \
+    "v_lshlrev_b32_e64 %[t2], %[t], -1\n"                                                       \
+    "v_bfe_u32 %[cx], %[px], %[t], 1\n"         /* :137-143 */                                  \
+    "v_bfe_u32 %[cy], %[py], %[t], 1\n"                                                         \
+    "v_bfe_u32 %[cz], %[pz], %[t], 1\n"                                                         \
+    "v_and_b32_e32 %[px], %[px], %[t2]\n"                                                       \
+    "v_and_b32_e32 %[py], %[py], %[t2]\n"                                                       \
+    "v_and_b32_e32 %[pz], %[pz], %[t2]\n"                                                       \
+    "v_lshl_or_b32 %[co], %[cy], 1, %[cx]\n"                                                    \
+    "v_lshl_or_b32 %[co], %[cz], 2, %[co]\n"                                                    \
     "s_waitcnt lgkmcnt(0)\n"                                                                    \
-    "v_lshlrev_b32_e32 %[t], 3, v42\n"                                                          \
-    "global_load_dwordx2 v[46:47], %[t], %[nodes]\n"                                            \
+    VRC_WALK_LOAD_NODE                                                                          \
     "Lwalk_next%=:\n"                                                                           \
     "s_mov_b64 exec, %[srun]\n"                                                                 \
     "s_cbranch_execnz Lwalk_loop%=\n"                                                           \
@@ -213,6 +215,7 @@ namespace vrc {
 // `stk` = this lane's column of the LDS stack, rows of 256 lanes (2 KiB apart).
 // COUNT_LANE: r.complexity is maintained (per lane); otherwise it is left alone and the return value is the number of
 // loop iterations all the wave's lanes executed in this call together (the same value in every lane that made the call).
+// r.h is not maintained (see the push above); nothing reads it after a walk.
 template <int LOD_MODE, bool COUNT_LANE>
 __device__ __forceinline__ uint32_t ray_walk(Ray& r, bool active, const uint2* __restrict__ nodes, uint2* stk,
                                              int depth, float coef, float bias)
@@ -224,41 +227,43 @@ __device__ __forceinline__ uint32_t ray_walk(Ray& r, bool active, const uint2* _
     const uint32_t stkb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint2*)stk
                           - (uint32_t)(SVO_MAX - depth + 1) * 2048u;
     const uint32_t sfc = 104u << 23;            // (scale - 23 + 127) << 23 = (scale << 23) + (104 << 23)
-    uint64_t sentry, sleaf, slod, srun, sin_, schild, stm, st;   // schild / stm double as the x / y step masks of the advance
+    const walk_rsrc_t rsrc = walk_node_rsrc(nodes);
+    uint64_t sentry, sleaf, slod, srun, sin_, sx, sy, st;   // sx / sy: the x / y step masks of the advance
     uint32_t siter, cs, m, t, t2, kind = 0u, ssteps = 0u, sb;
-    float tc;
-    float tcx = r.tcx, tcy = r.tcy, tcz = r.tcz, tox = r.tox, toy = r.toy, toz = r.toz;
-    float px = r.px, py = r.py, pz = r.pz, t_min = r.t_min, t_max = r.t_max, sf = r.scale_f, h = r.h;
+    float tc, cx, cy, cz, hx, hy, hz;
+    float px = r.px, py = r.py, pz = r.pz, t_min = r.t_min, t_max = r.t_max, sf = r.scale_f;
     uint32_t pid = r.parent_id, ndx = r.nd.x, ndy = r.nd.y;
-    uint32_t scale = (uint32_t)r.scale, co = r.child_offset, normal = r.normal, cmpl = COUNT_LANE ? r.complexity : 0u;
+    uint32_t sp = stkb + ((uint32_t)r.scale << 11);          // the level, as the LDS address of its stack row
+    uint32_t co = r.child_offset, normal = r.normal, cmpl = COUNT_LANE ? r.complexity : 0u;
 #define VRC_WALK_OPERANDS(COUNT_OPERANDS)                                                                         \
-        : [kind] "+v"(kind), COUNT_OPERANDS, [scale] "+v"(scale), [co] "+v"(co), [normal] "+v"(normal),              \
-          "+{v38}"(px), "+{v39}"(py), "+{v40}"(pz), "+{v41}"(t_min), "+{v42}"(pid), "+{v43}"(t_max),                  \
-          "+{v44}"(sf), "+{v45}"(h), "+{v46}"(ndx), "+{v47}"(ndy),                                                    \
+        : [kind] "+&v"(kind), COUNT_OPERANDS, [sp] "+&v"(sp), [co] "+&v"(co), [normal] "+&v"(normal),                     \
+          [px] "+&v"(px), [py] "+&v"(py), [pz] "+&v"(pz), [tmin] "+&v"(t_min), "+{v42}"(pid), "+{v43}"(t_max),            \
+          [sf] "+&v"(sf), "+{v46}"(ndx), "+{v47}"(ndy),                                                                \
           [sentry] "=&s"(sentry), [sleaf] "=&s"(sleaf), [slod] "=&s"(slod), [srun] "=&s"(srun), [sin] "=&s"(sin_),    \
-          [schild] "=&s"(schild), [stm] "=&s"(stm), [st] "=&s"(st),                                                   \
-          [siter] "=&s"(siter), [cs] "=&v"(cs), [m] "=&v"(m), [t] "=&v"(t), [t2] "=&v"(t2), [tc] "=&v"(tc)            \
-        : "{v32}"(tcx), "{v33}"(tcy), "{v34}"(tcz), "{v35}"(toz), "{v36}"(tox), "{v37}"(toy),                         \
-          [mirror] "v"(r.mirror), [stkb] "v"(stkb), [nodes] "s"(nodes), [sfc] "s"(sfc), [coef] "v"(coef), [bias] "v"(bias), \
+          [sx] "=&s"(sx), [sy] "=&s"(sy), [st] "=&s"(st),                                                             \
+          [siter] "=&s"(siter), [cs] "=&v"(cs), [m] "=&v"(m), [t] "=&v"(t), [t2] "=&v"(t2), [tc] "=&v"(tc),           \
+          [cx] "=&v"(cx), [cy] "=&v"(cy), [cz] "=&v"(cz), [hx] "=&v"(hx), [hy] "=&v"(hy), [hz] "=&v"(hz)              \
+        : [tcx] "v"(r.tcx), [tcy] "v"(r.tcy), [tcz] "v"(r.tcz), [tox] "v"(r.tox), [toy] "v"(r.toy), [toz] "v"(r.toz), \
+          [mirror] "v"(r.mirror), [stkb] "v"(stkb), [rsrc] "s"(rsrc), [nodes] "s"(nodes), [sfc] "s"(sfc), [coef] "v"(coef), [bias] "v"(bias), \
           [sact] "s"(sact)                                                                                             \
-        : "v48", "v49", "v50", "v51", "v52", "v53", "vcc", "scc", "memory"
-#define VRC_WALK_OPS_LANE [cmpl] "+v"(cmpl)
-#define VRC_WALK_OPS_WAVE [ssteps] "+s"(ssteps), [sb] "=&s"(sb)
+        : "vcc", "scc", "memory"
+#define VRC_WALK_OPS_LANE [cmpl] "+&v"(cmpl)
+#define VRC_WALK_OPS_WAVE [ssteps] "+&s"(ssteps), [sb] "=&s"(sb)
     if (COUNT_LANE) {
-        if (LOD_MODE == 0) asm volatile(VRC_WALK_ASM(VRC_WALK_SPAN_MIN, VRC_WALK_LOD_NONE, VRC_WALK_TMAX_MIN, VRC_WALK_COUNT_LANE) VRC_WALK_OPERANDS(VRC_WALK_OPS_LANE));
-        else if (LOD_MODE == 1) asm volatile(VRC_WALK_ASM(VRC_WALK_SPAN_CMP, VRC_WALK_LOD_COEF, VRC_WALK_TMAX_CMP, VRC_WALK_COUNT_LANE) VRC_WALK_OPERANDS(VRC_WALK_OPS_LANE));
-        else asm volatile(VRC_WALK_ASM(VRC_WALK_SPAN_CMP, VRC_WALK_LOD_FULL, VRC_WALK_TMAX_CMP, VRC_WALK_COUNT_LANE) VRC_WALK_OPERANDS(VRC_WALK_OPS_LANE));
+        if (LOD_MODE == 0) asm volatile(VRC_WALK_ASM(VRC_WALK_SPAN_NOLOD, VRC_WALK_TMAX_NOLOD, VRC_WALK_COUNT_LANE) VRC_WALK_OPERANDS(VRC_WALK_OPS_LANE));
+        else if (LOD_MODE == 1) asm volatile(VRC_WALK_ASM(VRC_WALK_SPAN_LOD(VRC_WALK_BIAS_NONE), VRC_WALK_TMAX_LOD, VRC_WALK_COUNT_LANE) VRC_WALK_OPERANDS(VRC_WALK_OPS_LANE));
+        else asm volatile(VRC_WALK_ASM(VRC_WALK_SPAN_LOD(VRC_WALK_BIAS_ADD), VRC_WALK_TMAX_LOD, VRC_WALK_COUNT_LANE) VRC_WALK_OPERANDS(VRC_WALK_OPS_LANE));
     } else {
-        if (LOD_MODE == 0) asm volatile(VRC_WALK_ASM(VRC_WALK_SPAN_MIN, VRC_WALK_LOD_NONE, VRC_WALK_TMAX_MIN, VRC_WALK_COUNT_WAVE) VRC_WALK_OPERANDS(VRC_WALK_OPS_WAVE));
-        else if (LOD_MODE == 1) asm volatile(VRC_WALK_ASM(VRC_WALK_SPAN_CMP, VRC_WALK_LOD_COEF, VRC_WALK_TMAX_CMP, VRC_WALK_COUNT_WAVE) VRC_WALK_OPERANDS(VRC_WALK_OPS_WAVE));
-        else asm volatile(VRC_WALK_ASM(VRC_WALK_SPAN_CMP, VRC_WALK_LOD_FULL, VRC_WALK_TMAX_CMP, VRC_WALK_COUNT_WAVE) VRC_WALK_OPERANDS(VRC_WALK_OPS_WAVE));
+        if (LOD_MODE == 0) asm volatile(VRC_WALK_ASM(VRC_WALK_SPAN_NOLOD, VRC_WALK_TMAX_NOLOD, VRC_WALK_COUNT_WAVE) VRC_WALK_OPERANDS(VRC_WALK_OPS_WAVE));
+        else if (LOD_MODE == 1) asm volatile(VRC_WALK_ASM(VRC_WALK_SPAN_LOD(VRC_WALK_BIAS_NONE), VRC_WALK_TMAX_LOD, VRC_WALK_COUNT_WAVE) VRC_WALK_OPERANDS(VRC_WALK_OPS_WAVE));
+        else asm volatile(VRC_WALK_ASM(VRC_WALK_SPAN_LOD(VRC_WALK_BIAS_ADD), VRC_WALK_TMAX_LOD, VRC_WALK_COUNT_WAVE) VRC_WALK_OPERANDS(VRC_WALK_OPS_WAVE));
     }
 #undef VRC_WALK_OPS_LANE
 #undef VRC_WALK_OPS_WAVE
 #undef VRC_WALK_OPERANDS
-    r.px = px; r.py = py; r.pz = pz; r.t_min = t_min; r.t_max = t_max; r.scale_f = sf; r.h = h;
+    r.px = px; r.py = py; r.pz = pz; r.t_min = t_min; r.t_max = t_max; r.scale_f = sf;
     r.parent_id = pid; r.nd = make_uint2(ndx, ndy);
-    r.scale = (int)scale; r.child_offset = co; r.normal = normal;
+    r.scale = (int)((sp - stkb) >> 11); r.child_offset = co; r.normal = normal;
     if (COUNT_LANE) r.complexity = cmpl;
     r.kind = kind;                              // 0 for a lane without a ray, as ray_setup left it
     r.shift = co ^ r.mirror;                    // child_shift of the child that was hit (unused on a miss)
