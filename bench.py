@@ -12,7 +12,7 @@ actually executed (counted by the kernel, equal to the oracle's count).
 
 Frames are independent, and a launch of the persistent frame kernel is mostly
 tail at its end: the last work units finish at latency speed while most of the
-chip idles (~4 % of a 1080p frame on one GPU, more on a multi-GPU shard).  So two
+chip idles (~4 % of a 1080p frame on one GPU, more on a multi-GPU shard).  So
 three renderers / streams take turns by default (`--inflight 3`): the end of one
 launch overlaps the start of the next frames, just as the exchange of frame i
 overlaps the renders after it.  ms_per_step is then the steady-state frame PERIOD
@@ -78,12 +78,16 @@ def kernel_source_hash():
         with open(os.path.join(ROOT, "cpuvoxelraycaster_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     h.update(" ".join(build.FLAGS).encode())
+    extra = os.environ.get("VRC_EXTRA_FLAGS", "").strip()       # experiment builds (tools/ab_variants.sh) never match the product's record
+    if extra:
+        h.update(("|" + extra).encode())
     return h.hexdigest()[:16]
 
 
-def pmc_record(key):
+def pmc_record(key, kernel=None, fused=None, inflight=None):
     """The rocprofv3 PMC record of this workload from profiles/traffic.json (tools/pmc_roofline.sh +
-    tools/update_traffic.py), or (None, reason) when there is none FOR THE KERNEL SOURCES OF THIS TREE."""
+    tools/update_traffic.py), or (None, reason) when there is none FOR THE KERNEL SOURCES OF THIS TREE, or when it was taken on
+    another build of the frame kernel / other bench settings than this run's."""
     prof = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         rec = json.load(open(prof)).get("entries", {}).get(key)
@@ -95,6 +99,13 @@ def pmc_record(key):
     if rec.get("source_hash") != cur:
         return None, (f"profiles/traffic.json[{key}] was measured on kernel sources {rec.get('source_hash')} (commit "
                       f"{rec.get('commit')}); this tree's are {cur}: re-run tools/pmc_roofline.sh + tools/update_traffic.py")
+    if kernel and rec.get("kernel") and rec["kernel"] != kernel:
+        return None, f"profiles/traffic.json[{key}] was measured on {rec['kernel']}, this run launches {kernel}"
+    st = rec.get("settings") or {}
+    if fused is not None and st.get("fused") is not None and bool(st["fused"]) != bool(fused):
+        return None, f"profiles/traffic.json[{key}] was measured with fused resolve = {st['fused']}, this run has {fused}"
+    if inflight is not None and st.get("frames_in_flight") is not None and int(st["frames_in_flight"]) != int(inflight):
+        return None, f"profiles/traffic.json[{key}] was measured with {st['frames_in_flight']} frames in flight, this run has {inflight}"
     return rec, None
 
 
@@ -221,6 +232,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--pitch", type=float, default=-0.5)
+    ap.add_argument("--blocks", type=int, default=5, help="timed blocks of `steps` frames each (the median block is reported)")
+    ap.add_argument("--blocks-min-seconds", type=float, default=0.5, help="keep timing blocks until this much has been timed (max 64 blocks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inflight", type=int, default=0,
                     help="frames in flight per GPU (renderers / streams used round-robin); 1 = one stream, each frame starts "
@@ -416,20 +429,41 @@ def main():
     drain()
     for r in rcs:
         r.stats(reset=True, stream=tstreams[0].cuda_stream)
-    if dist_on:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-    host_enqueue_us = (time.perf_counter() - t0) / args.steps * 1e6   # host time to issue a frame (no waiting on the GPU unless a slot is busy)
-    drain()                                                    # the last frames' gathers are inside the timed region
-    if dist_on:
-        dist.barrier()
+    # The timed region: exactly `steps` frames between a barrier + synchronize on both sides -- and that block repeated
+    # (at least 5 times, and until 0.5 s have been timed) so that one run reports a spread: ms_per_step is the MEDIAN block,
+    # extra.ms_per_step_blocks = [min, median, max] (round-2 verdict: a 26 ms window is one sample).
+    blocks = []            # (elapsed seconds, host enqueue us per step, per-rank stats of the block, events of the block)
+    n_blocks = max(1, args.blocks)
+    while len(blocks) < n_blocks:
+        for r in rcs:
+            r.stats(reset=True, stream=tstreams[0].cuda_stream)
+        del ev_pairs[:]
+        if dist_on:
+            dist.barrier()
         torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(True)
+        enq_us = (time.perf_counter() - t0) / args.steps * 1e6   # host time to issue a frame (no waiting on the GPU unless a slot is busy)
+        drain()                                                # the last frames' gathers are inside the timed region
+        if dist_on:
+            dist.barrier()
+            torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if dist_on:                                            # the slowest rank's clock decides, block by block
+            t = torch.tensor([el], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        blocks.append((el, enq_us, [r.stats(stream=tstreams[0].cuda_stream) for r in rcs], list(ev_pairs)))
+        if len(blocks) == 1 and args.blocks_min_seconds > 0:   # from the first block's (rank-agreed) time: the same count on every rank
+            n_blocks = min(64, max(n_blocks, int(args.blocks_min_seconds / max(el, 1e-6)) + 1))
+    order = sorted(range(len(blocks)), key=lambda k: blocks[k][0])
+    med = order[len(order) // 2]                               # the median block is the one reported
+    elapsed, host_enqueue_us, sts, med_events = blocks[med]
+    del ev_pairs[:]
+    ev_pairs.extend(med_events)
+    block_ms = [b[0] / args.steps * 1e3 for b in blocks]
     stream = tstreams[0].cuda_stream
-    sts = [r.stats(stream=stream) for r in rcs]
 
     class _Sum:
         rays = sum(x.rays for x in sts)
@@ -447,9 +481,6 @@ def main():
 
     rays, steps_sum, pixels = st.rays, st.sum_complexity, st.pixels
     if dist_on:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
         c = torch.tensor([rays, steps_sum, pixels], dtype=torch.int64, device="cuda")
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         rays, steps_sum, pixels = (int(v) for v in c.tolist())
@@ -512,28 +543,37 @@ def main():
         rc1 = make_renderer(whole=False)                        # the library's own unit policy for a launch alone on the chip
         ts = tstreams[0]
         n1 = max(10, min(args.steps, 50))
-        evs = []
+        runs = []                                               # (ms per step, kernel ms, rays per frame) of each block
         with torch.cuda.stream(ts):
-            for i in range(3 + n1):
-                if i == 3:
-                    torch.cuda.synchronize()
-                    t1 = time.perf_counter()
+            for i in range(3):                                  # untimed
                 rc1.frame_index = i * spp
-                ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                ea.record(ts)
                 rc1.renderFrame(cam, spp=spp, stream=ts.cuda_stream)
-                eb.record(ts)
                 rc1.resolveShard(reset=True, stream=ts.cuda_stream)
-                if i >= 3:
+            for blk in range(max(3, args.blocks)):
+                evs = []
+                rc1.stats(reset=True, stream=ts.cuda_stream)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for i in range(n1):
+                    rc1.frame_index = (3 + blk * n1 + i) * spp
+                    ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    ea.record(ts)
+                    rc1.renderFrame(cam, spp=spp, stream=ts.cuda_stream)
+                    eb.record(ts)
+                    rc1.resolveShard(reset=True, stream=ts.cuda_stream)
                     evs.append((ea, eb))
-            torch.cuda.synchronize()
-            dt1 = time.perf_counter() - t1
-        st1 = rc1.stats(stream=ts.cuda_stream)
+                torch.cuda.synchronize()
+                dt1 = time.perf_counter() - t1
+                runs.append((dt1 / n1 * 1e3, sum(a.elapsed_time(b) for a, b in evs) / len(evs), rc1.stats(stream=ts.cuda_stream).rays / n1))
+        runs.sort()
+        m1 = runs[len(runs) // 2]
         extras["one_frame_in_flight"] = {
-            "ms_per_step": round(dt1 / n1 * 1e3, 4), "kernel_ms": round(sum(a.elapsed_time(b) for a, b in evs) / len(evs), 4),
-            "value": round(st1.rays / (3 + n1) * n1 / dt1 / 1e6, 2), "unit": "Mrays/s", "steps": n1,
+            "ms_per_step": round(m1[0], 4), "kernel_ms": round(m1[1], 4),
+            "value": round(m1[2] / (m1[0] * 1e-3) / 1e6, 2), "unit": "Mrays/s", "steps": n1,
+            "ms_per_step_blocks": [round(runs[0][0], 4), round(m1[0], 4), round(runs[-1][0], 4)], "blocks": len(runs),
+            "kernel": rc1.lastKernel(),
             "note": "--inflight 1: one stream, each frame starts when the previous one has ended; the library's automatic work-unit "
-                    "policy, resolve as a second kernel"}
+                    "policy, resolve as a second kernel; median block of `blocks` (min / median / max in ms_per_step_blocks)"}
     if rank == 0 and world == 1 and not dist_on and not args.no_extras and args.config == "c3":
         # the same way as the timed region: F renderers / streams round-robin, same unit policy, same resolve
         rcs2 = [make_renderer() for _ in range(F)]
@@ -617,7 +657,7 @@ def main():
         # passes recorded in profiles/traffic.json -- only when that record was taken on THIS tree's kernel sources
         # (the stage-synchronous kernel has a specialisation for the pinhole camera, see csrc/vrc_kernels.hip launch_render)
         sync_kernel_name = rcs[0].lastKernel()       # the build the library chose for this kind of launch (vrc_renderer_last_kernel)
-        rec, why = pmc_record(f"{args.config}_n{world}" + ("" if F > 1 else "_inflight1")) if args.kernel == 2 else (None, "PMC record exists for k_render_sync only")
+        rec, why = pmc_record(f"{args.config}_n{world}" + ("" if F > 1 else "_inflight1"), kernel=sync_kernel_name, fused=fused, inflight=F) if args.kernel == 2 else (None, "PMC record exists for k_render_sync only")
         traffic = rec["traffic_bytes"] if rec else None
         roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
@@ -645,6 +685,52 @@ def main():
                                      "..._timed = this run's kernel_ms x 2.4 GHz x 1024 SIMDs / SQ_INSTS_VALU (launches overlapping as timed)"}
         else:
             roof["traffic_note"] = why
+        # The binding limit is instruction issue, not bandwidth: price the launch against the issue floor as well
+        # (tools/issue_model.py: instruction classes of the walk loop x block issue frequencies; counts from the PMC record
+        # where there is one).  `bound` names it; frac / achieved / peak keep the HBM form SURVEY 8d asks for.
+        issue = roof.setdefault("issue", {})
+        try:
+            model = json.load(open(os.path.join(ROOT, "profiles", "issue_model.json")))
+        except Exception as e:                                   # noqa: BLE001
+            model = None
+            issue["floor_note"] = f"profiles/issue_model.json unreadable: {e}"
+        if model is not None and model.get("source_hash") != kernel_source_hash():
+            issue["floor_note"] = (f"profiles/issue_model.json was made from kernel sources {model.get('source_hash')}, this tree's are "
+                                   f"{kernel_source_hash()}: re-run tools/issue_model.py")
+            model = None
+        if model is not None and not (args.config in ("c3",) and abs(args.pitch + 0.5) < 1e-9 and args.kernel == 2):
+            issue["floor_note"] = "block issue frequencies exist for the c3 workload at pitch -0.5 only (tests/tools/path_schedule.py --dump)"
+            model = None
+        if model is not None:
+            cyc = model["cycles"]
+            tile_samples = my_pixels_per_launch / 64.0 * spp      # 8 x 8 pixel tiles x samples of this rank's launch
+            w = model["walks_per_tile_sample"]
+            walk_valu = sum(w.get(c, 0.0) for c in "ABSQP") * tile_samples
+            slow = w.get("Q", 0.0) * tile_samples
+            pcls = w.get("P", 0.0) * tile_samples
+            valu = float(rec["valu_wave_instr"]) if rec and rec.get("valu_wave_instr") else walk_valu
+            scalar = (float(rec["sq_insts_salu"] + rec.get("sq_insts_branch", 0)) if rec and rec.get("sq_insts_salu")
+                      else (w.get("salu", 0.0) + w.get("branch", 0.0)) * tile_samples)
+            simds, cus, hz = 1024.0, 256.0, 2.4e9
+            res = {"valu_issue": cyc["valu_arch"] * valu / simds, "slow_class_unit": (cyc["slow"] * slow + cyc["p"] * pcls) / simds,
+                   "scalar_unit": cyc["salu_per_cu"] * scalar / cus}
+            binding = max(res, key=res.get)
+            floor_ms = res[binding] / hz * 1e3
+            issue.update({
+                "floor_ms": round(floor_ms, 4), "issue_frac": round(floor_ms / kernel_ms, 4), "binding_resource": binding,
+                "floor_ms_by_resource": {k: round(v / hz * 1e3, 4) for k, v in res.items()},
+                "floor_ms_at_measured_ceiling": round(cyc["valu_measured_ceiling"] * valu / simds / hz * 1e3, 4),
+                "valu_wave_instr_walks_model": int(walk_valu), "slow_class_wave_instr_walks_model": int(slow),
+                "valu_wave_instr_used": int(valu), "valu_count_from": "rocprofv3 SQ_INSTS_VALU (profiles/traffic.json)" if rec and rec.get("valu_wave_instr") else "model (walks only: a lower bound)",
+                "floor_is": f"max over resources of the cycles below which the launch's instruction streams cannot issue: {cyc['valu_arch']} cycles per VALU "
+                            f"wave-instruction per SIMD (a wave64 instruction is two passes of the SIMD-32, MI355X_MICROARCH.md), {cyc['slow']} per "
+                            f"slow-class instruction (compares, min / max, shift-or ..., tools/micro/op_issue.hip), {cyc['salu_per_cu']} per scalar / branch "
+                            "instruction of a CU's one scalar unit; 1024 SIMDs, 256 CUs, 2.4 GHz.  floor_ms_at_measured_ceiling prices VALU issue at "
+                            f"{cyc['valu_measured_ceiling']} cycles, the fastest any plain-VALU stream issued in the microbenchmarks (profiles/r03/op_pairs.txt) -- "
+                            "the kernel's own streams issue at about that rate, i.e. only fewer instructions (or fuller lanes, see lane_utilisation) make the frame faster"})
+            roof["bound"] = "valu_issue"
+            roof["bound_note"] = ("instruction issue (roofline.issue) is what binds; achieved / peak / frac keep the nominal HBM form SURVEY 8d "
+                                  "asks for (algorithmic bytes / kernel time), traffic is the measured HBM traffic")
         out = {
             "metric": "Mrays/s + ms/frame, 512^3 LSVO @1920x1080 4spp GI, 1/2/4/8 GPU",
             "value": round(rays / elapsed / 1e6, 2),
@@ -670,6 +756,10 @@ def main():
             if "ms_per_step" in other:
                 other["value"] = round(rays / args.steps / (other["ms_per_step"] * 1e-3) / 1e6, 2)
             extras["other_exchange_form"] = other
+        extras["ms_per_step_blocks"] = {"min_median_max": [round(min(block_ms), 4), round(sorted(block_ms)[len(block_ms) // 2], 4), round(max(block_ms), 4)],
+                                        "blocks": len(block_ms), "steps_per_block": args.steps,
+                                        "note": "every block is `steps` frames between barrier + synchronize on both sides; ms_per_step, value and the "
+                                                "roofline are those of the median block"}
         if extras:
             out["extra"] = extras
         if world == 1 and not args.no_cpu_baseline:

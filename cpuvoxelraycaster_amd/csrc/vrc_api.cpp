@@ -574,6 +574,7 @@ int render_impl(vrc_renderer* r, const vrc_camera* cam, const vrc_frame_params* 
     a.chunk = tuning.chunk;
     a.refill_threshold = tuning.refill_threshold;
     if (a.n_items == 0) return VRC_OK;
+    int queue_used = -1;
     {
         uint32_t* sets[2] = {a.queue, a.queue + vrc::VRC_QUEUE_BYTES / 4};
         if (tuning.kernel == VRC_KERNEL_SYNC) {
@@ -583,12 +584,14 @@ int render_impl(vrc_renderer* r, const vrc_camera* cam, const vrc_frame_params* 
             if (!r->queue_zero[use]) HIP_TRY(hipMemsetAsync(sets[use], 0, vrc::VRC_QUEUE_BYTES, st));
             a.queue = sets[use];
             a.queue_other = sets[1 - use];
-            r->queue_zero[use] = false;
-            r->queue_zero[1 - use] = true;
+            queue_used = use;
         } else {
             if (!r->queue_zero[0]) HIP_TRY(hipMemsetAsync(sets[0], 0, vrc::VRC_QUEUE_BYTES, st));
-            r->queue_zero[0] = false;
         }
+        // Until the launch is known to have been enqueued neither set counts as zero: the other set is only zeroed BY this
+        // launch (its block 0), so an error exit below must not leave it marked ready -- the next frame would take heads that
+        // still hold the previous frame's consumed counts, render nothing and resolve a stale image.
+        r->queue_zero[0] = r->queue_zero[1] = false;
     }
     a.fused_resolve = fused ? 1u : 0u;
     a.reuse_invariant = tuning.reuse_invariant ? 1u : 0u;
@@ -649,6 +652,7 @@ int render_impl(vrc_renderer* r, const vrc_camera* cam, const vrc_frame_params* 
     }
     const uint32_t grid = (uint32_t)(want < cap ? want : cap);
     HIP_TRY(vrc::launch_render(a, grid, (int)tuning.kernel, st, &r->last_kernel));
+    if (queue_used >= 0) r->queue_zero[1 - queue_used] = true;           // zeroed by the launch that is now in the stream
     return VRC_OK;
 }
 }  // namespace

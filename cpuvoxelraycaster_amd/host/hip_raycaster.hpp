@@ -16,7 +16,6 @@
 
 #include <cstdint>
 #include <fstream>
-#include <list>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -282,7 +281,7 @@ private:
 };
 
 // Progressive frames kept in flight -- for hosts that do not need frame i before they issue
-// frame i + 1: an offline render, a replay (ReplayElements below), a multi-GPU shard.  `frames_in_flight` renderers and
+// frame i + 1: an offline render, a replay (readReplay below), a multi-GPU shard.  `frames_in_flight` renderers and
 // streams take turns; a work unit is a tile's whole sample set and the resolve is fused into the frame kernel, which is the
 // fastest form once launches overlap.  submit() returns at once; image(slot) waits for that slot's frame only.  Frame n
 // is the frame a single HipRayCaster would render n-th with the same spp (frame_index = n * spp), bit for bit.
@@ -364,47 +363,53 @@ public:
     {
         const float old_value_conservation = raycaster.use_samples ? 0.0f : 0.1f;
         check(vrc_present(p_, raycaster.handle(), old_value_conservation, median, stream), "vrc_present");
+        last_stream_ = stream;
     }
     void* window_device_ptr() const { return vrc_presenter_window_ptr(p_); }
+    // Copies the window image out, ordered after the last present(): the read runs on THAT call's stream (frame streams are
+    // non-blocking, the NULL stream does not wait for them).
     std::vector<uint8_t> window() const
     {
         std::vector<uint8_t> img((size_t)out_w_ * out_h_ * 4);
-        check(vrc_presenter_read(p_, img.data(), nullptr, nullptr), "vrc_presenter_read");
+        check(vrc_presenter_read(p_, img.data(), nullptr, last_stream_), "vrc_presenter_read");
         return img;
     }
 
 private:
     vrc_presenter* p_ = nullptr;
     uint32_t out_w_, out_h_;
+    void* last_stream_ = nullptr;
 };
 
-// Camera-path replay (include/replay.hpp:8-35): whitespace-separated ticks
-// `t x y z view_x view_y`; reading stops at the first malformed tick, a missing
-// file gives an empty list.  The reference has the reader but no caller; here it
-// feeds deterministic multi-frame runs (tools/replay_bench.py speaks the same format).
-struct ReplayElements {
-    float timestamp, x, y, z, view_x, view_y;
-
-    static std::list<ReplayElements> loadFromFile(const std::string& filename)
-    {
-        std::ifstream file(filename);
-        std::list<ReplayElements> result;
-        if (file) {
-            ReplayElements elem;
-            while (file >> elem.timestamp >> elem.x >> elem.y >> elem.z >> elem.view_x >> elem.view_y) result.push_back(elem);
-        }
-        return result;
-    }
-
-    CameraState camera(float aperture = 0.0f, float focal_length = 1.0f, float fov = 1.0f) const
-    {
-        CameraState c;
-        c.position = {x, y, z};
-        c.view_angle = {view_x, view_y};
-        c.aperture = aperture; c.focal_length = focal_length; c.fov = fov;
-        return c;
-    }
+// Camera-path replay files.  The format is the one include/replay.hpp:8-35 reads: whitespace-separated numbers, six per
+// tick (time, position x y z, view angles x y); a tick counts only when all six parse, reading ends at the first word that
+// is not a number, a missing file gives no ticks (pinned against the reference's reader: tests/golden/replay_cases.json).
+// Here a tick is what the renderer consumes -- a time and a camera pose; the lens values, which the file does not carry,
+// come from the caller.  The reference has the reader but no caller; this one feeds deterministic multi-frame runs
+// (tests/cpp/replay_main.cpp; tools/replay_bench.py speaks the same format).
+struct ReplayTick {
+    float time = 0.0f;
+    CameraState pose;
 };
+
+inline std::vector<ReplayTick> readReplay(const std::string& path, float aperture = 0.0f, float focal_length = 1.0f, float fov = 1.0f)
+{
+    std::vector<ReplayTick> ticks;
+    std::ifstream in(path);
+    for (;;) {
+        float v[6];
+        int got = 0;
+        while (got < 6 && (in >> v[got])) ++got;
+        if (got < 6) break;
+        ReplayTick t;
+        t.time = v[0];
+        t.pose.position = {v[1], v[2], v[3]};
+        t.pose.view_angle = {v[4], v[5]};
+        t.pose.aperture = aperture; t.pose.focal_length = focal_length; t.pose.fov = fov;
+        ticks.push_back(t);
+    }
+    return ticks;
+}
 
 }  // namespace vrc_host
 

@@ -272,7 +272,9 @@ int vrc_present_image(vrc_presenter *p, const void *image_dev, float old_value_c
 int vrc_presenter_clear(vrc_presenter *p, void *stream);          /* denoised_tex = 0 */
 void *vrc_presenter_window_ptr(vrc_presenter *p);                 /* RGBA8 out_width x out_height, device */
 void *vrc_presenter_denoised_ptr(vrc_presenter *p);               /* RGBA8 width x height, device */
-/* Copies the window image and / or denoised_tex to host memory (either may be NULL).  Synchronous. */
+/* Copies the window image and / or denoised_tex to host memory (either may be NULL).  Synchronous.  `stream` must be the
+ * stream of the vrc_present call whose result is wanted (or one ordered after it): streams made by vrc_stream_create are
+ * non-blocking, so a read on the NULL stream does not wait for a present issued on one of them. */
 int vrc_presenter_read(vrc_presenter *p, uint8_t *window_rgba_host, uint8_t *denoised_rgba_host, void *stream);
 
 /* Self-test of the arithmetic shortcuts: the kernels compute -1 / |d| (lsvo.hpp:47), glm::normalize's 1 / sqrt and

@@ -1,5 +1,5 @@
 // Camera-path replay through the C++ host adapter: the reference's reader
-// (include/replay.hpp:18-33, restated as vrc_host::ReplayElements::loadFromFile) feeds
+// (include/replay.hpp:18-33, restated as vrc_host::readReplay) feeds
 // HipRayCaster::renderFrame tick by tick -- what a headless main.cpp would do with the replay file.
 // Prints one line per frame for the pytest wrapper to compare with the oracle.  With a ninth argument F > 0 the ticks go
 // through vrc_host::HipFramePipeline with F frames in flight instead (same lines, frame for frame), and `reuse` as a
@@ -30,7 +30,7 @@ int main(int argc, char** argv)
     const std::vector<char> top = slurp(argv[3]), side = slurp(argv[4]);
     const uint32_t W = (uint32_t)atoi(argv[5]), H = (uint32_t)atoi(argv[6]), spp = (uint32_t)atoi(argv[7]);
     try {
-        const std::list<vrc_host::ReplayElements> ticks = vrc_host::ReplayElements::loadFromFile(argv[8]);
+        const std::vector<vrc_host::ReplayTick> ticks = vrc_host::readReplay(argv[8]);
         std::printf("%zu ticks loaded\n", ticks.size());                            // replay.hpp:30
         vrc_host::HipLSVO lsvo((const vrc_lnode*)nodes.data(), nodes.size() / sizeof(vrc_lnode), depth, 0);
         vrc_host::check(vrc_scene_set_textures(lsvo.handle(), (const uint8_t*)top.data(), (const uint8_t*)side.data()), "textures");
@@ -48,15 +48,15 @@ int main(int argc, char** argv)
             pipe.setLightPosition(light);
             pipe.setUseGI(true);
             pipe.setInvariantRayReuse(reuse);
-            const std::vector<vrc_host::ReplayElements> tv(ticks.begin(), ticks.end());
+            const std::vector<vrc_host::ReplayTick>& tv = ticks;
             const size_t F = pipe.framesInFlight();
             for (size_t i = 0; i < tv.size() + F; ++i) {
                 if (i >= F) {                                        // frame i - F sits in the slot frame i is about to take
                     const uint32_t slot = (uint32_t)((i - F) % F);
                     const std::vector<uint8_t> img = pipe.image(slot);
-                    report((unsigned)(i - F), tv[i - F].timestamp, img, pipe.stats(slot, true));
+                    report((unsigned)(i - F), tv[i - F].time, img, pipe.stats(slot, true));
                 }
-                if (i < tv.size()) pipe.submit(tv[i].camera());
+                if (i < tv.size()) pipe.submit(tv[i].pose);
             }
             const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             std::printf("pipeline frames_in_flight=%zu ms_per_frame=%.4f\n", F, ms / (double)tv.size());
@@ -66,13 +66,13 @@ int main(int argc, char** argv)
         rc.setLightPosition(light);
         rc.use_gi = true; rc.use_samples = true;
         unsigned frame = 0;
-        for (const vrc_host::ReplayElements& e : ticks) {
-            const vrc_host::CameraState cam = e.camera();
+        for (const vrc_host::ReplayTick& e : ticks) {
+            const vrc_host::CameraState& cam = e.pose;
             rc.resetSamples();
             rc.renderFrame(cam, -1, spp);
             rc.samples_to_image();
             const std::vector<uint8_t> img = rc.render_image();
-            report(frame++, e.timestamp, img, rc.stats(true));
+            report(frame++, e.time, img, rc.stats(true));
         }
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         std::printf("sequential ms_per_frame=%.4f\n", ms / (double)(ticks.empty() ? 1 : ticks.size()));

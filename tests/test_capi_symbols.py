@@ -69,8 +69,8 @@ def test_replay_reader_matches_reference_format(built, tmp_path):
     good = tmp_path / "a.replay"
     good.write_text("0.0 1 2 3 0.1 -0.2\n0.5 4 5 6\n0.3 0.4\n1.0 7 8 9 x 0\n2.0 1 1 1 1 1\n")
     hdr = os.path.join(ROOT, "cpuvoxelraycaster_amd", "host", "hip_raycaster.hpp")
-    src = ('#include "%s"\n#include <cstdio>\nint main(int c, char** v){ auto l = vrc_host::ReplayElements::loadFromFile(v[1]);'
-           'std::printf("%%zu", l.size()); for (auto& e : l) std::printf(" %%g %%g %%g %%g %%g %%g", e.timestamp, e.x, e.y, e.z, e.view_x, e.view_y);'
+    src = ('#include "%s"\n#include <cstdio>\nint main(int c, char** v){ auto l = vrc_host::readReplay(v[1]);'
+           'std::printf("%%zu", l.size()); for (auto& e : l) std::printf(" %%g %%g %%g %%g %%g %%g", e.time, e.pose.position.x, e.pose.position.y, e.pose.position.z, e.pose.view_angle.x, e.pose.view_angle.y);'
            'return 0; }\n') % hdr
     exe = str(tmp_path / "replay_test")
     subprocess.run(["g++", "-std=c++14", "-x", "c++", "-", "-o", exe, "-L" + os.path.join(ROOT, "cpuvoxelraycaster_amd"),

@@ -93,6 +93,37 @@ def test_frame_limits_are_errors(built, heights, textures):
     assert L.vrc_set_tuning(9, 0, 0) == -1
 
 
+def test_failed_call_does_not_poison_the_next_frames(built, heights, textures):
+    """a call that fails after the work-queue bookkeeping (here: more work units than 32 bits number)
+    must not leave a queue set marked as zeroed that no launch ever zeroed -- the frames after it would find every head
+    exhausted, render nothing and resolve a stale image."""
+    import cpuvoxelraycaster_amd as vrc
+    svo = vrc.LSVO(vrc.build_terrain_lsvo(heights, 7), 7, textures=textures)
+    cam = vrc.reference_camera(7, pitch=-0.5)
+    W, H = 3840, 2160
+
+    def make():
+        rc = vrc.RayCaster(svo, (W, H))
+        rc.setLightPosition(vrc.reference_light(7))
+        rc.use_gi = rc.use_samples = True
+        rc.shadow_samples = 1
+        return rc
+
+    good, bad = make(), make()
+    for rc in (good, bad):
+        rc.renderFrameResolved(cam, spp=2)
+    bad.setSampleChunk(1)
+    with pytest.raises(vrc.VrcError, match="work units"):
+        bad.renderFrameResolved(cam, spp=65536)           # 129 600 tiles x 65 536 units
+    bad.setSampleChunk(0)
+    for f in range(3):                                    # both queue sets come round
+        for rc in (good, bad):
+            rc.renderFrameResolved(cam, spp=2)
+        assert np.array_equal(bad.readImage(), good.readImage()), f
+        sg, sb = good.stats(), bad.stats()
+        assert (sb.rays, sb.sum_complexity, sb.pixels) == (sg.rays, sg.sum_complexity, sg.pixels)
+
+
 def test_scheduling_knobs_belong_to_the_renderer(built, heights, textures):
     """Two renderers on one scene with different frame kernels / chunkings, used alternately: identical results;
     process-wide setters only seed renderers created afterwards."""

@@ -229,11 +229,11 @@ def test_reference_probe_sequence_random_and_gi_rays(nodes9):
 
 
 def _host_replay_reader(tmp_path):
-    """The product's reader: vrc_host::ReplayElements::loadFromFile (host/hip_raycaster.hpp), as a tiny executable."""
+    """The product's reader: vrc_host::readReplay (host/hip_raycaster.hpp), as a tiny executable."""
     import subprocess
     hdr = os.path.join(ROOT, "cpuvoxelraycaster_amd", "host", "hip_raycaster.hpp")
-    src = ('#include "%s"\n#include <cstdio>\n#include <cstring>\nint main(int c, char** v){ auto l = vrc_host::ReplayElements::loadFromFile(v[1]);'
-           'std::printf("%%zu", l.size()); for (auto& e : l) { float f[6] = {e.timestamp, e.x, e.y, e.z, e.view_x, e.view_y};'
+    src = ('#include "%s"\n#include <cstdio>\n#include <cstring>\nint main(int c, char** v){ auto l = vrc_host::readReplay(v[1]);'
+           'std::printf("%%zu", l.size()); for (auto& e : l) { float f[6] = {e.time, e.pose.position.x, e.pose.position.y, e.pose.position.z, e.pose.view_angle.x, e.pose.view_angle.y};'
            'for (float q : f) { unsigned u; std::memcpy(&u, &q, 4); std::printf(" %%u", u); } } return 0; }\n') % hdr
     exe = str(tmp_path / "replay_reader")
     subprocess.run(["g++", "-std=c++14", "-x", "c++", "-", "-o", exe, "-L" + os.path.join(ROOT, "cpuvoxelraycaster_amd"),

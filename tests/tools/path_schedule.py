@@ -26,6 +26,7 @@ def simulate(ops, length, policy, lod):
     pos = np.zeros(n, np.int64)           # next iteration of each lane
     waiting_pop = np.zeros(n, bool)       # header + advance done, pop outstanding
     cost = 0.0
+    blocks = np.zeros(4, np.int64)        # times the header / descend / advance / pop block was issued
     h_cost = H_ + (2.0 if lod else 0.0)
     k = policy.get("pop_every", 1)
     thr = policy.get("pop_threshold", 1)
@@ -38,12 +39,15 @@ def simulate(ops, length, policy, lod):
         if active.any():
             cur = ops[np.arange(n), np.minimum(pos, ops.shape[1] - 1)]
             cost += h_cost
+            blocks[0] += 1
             d = active & (cur == 0)
             a = active & ((cur == 1) | (cur == 2))
             if d.any():
                 cost += D_
+                blocks[1] += 1
             if a.any():
                 cost += A_
+                blocks[2] += 1
             need_pop = active & (cur == 2)
             waiting_pop |= need_pop
             pos[active & ~need_pop] += 1        # descend / plain advance / exit complete this round
@@ -58,8 +62,10 @@ def simulate(ops, length, policy, lod):
                 run_pop = nwait >= thr or not others
         if run_pop:
             cost += P_
+            blocks[3] += 1
             pos[waiting_pop] += 1
             waiting_pop[:] = False
+    policy["_blocks"] = policy.get("_blocks", np.zeros(4, np.int64)) + blocks
     return cost, rnd
 
 
@@ -68,6 +74,7 @@ def main():
     ap.add_argument("--band", type=int, default=32, help="render 1 / band of the 8-row blocks")
     ap.add_argument("--tiles", type=int, default=600)
     ap.add_argument("--threads", type=int, default=os.cpu_count() or 1)
+    ap.add_argument("--dump", default="", help="write the block issue frequencies of the shipped policy as JSON (tools/issue_model.py reads it)")
     a = ap.parse_args()
     import cpuvoxelraycaster_amd as vrc
     import oracle_lib as O
@@ -99,14 +106,32 @@ def main():
     names = ["primary", "shadow", "GI", "GI shadow"]
     tot = {k: np.zeros(4) for k in policies}
     rounds = {k: np.zeros(4) for k in policies}
+    shipped = "now (pop whenever a lane needs it)"
+    stage_blocks = np.zeros((4, 4), np.int64)       # [stage][header, descend, advance, pop] of the shipped policy
+    lane_iters = np.zeros(4, np.int64)
     for (b, tx) in tiles:
         for st in range(4):
             o = ops[b * 8:b * 8 + 8, tx * 8:tx * 8 + 8, st].reshape(64, LEN)
             ln = trace[b * 8:b * 8 + 8, tx * 8:tx * 8 + 8, st].reshape(64).astype(np.int64)
+            lane_iters[st] += ln.sum()
             for k, pol in policies.items():
+                pol.pop("_blocks", None)
                 c, r = simulate(o, ln, pol, lod=st >= 2)
                 tot[k][st] += c
                 rounds[k][st] += r
+                if k == shipped:
+                    stage_blocks[st] += pol["_blocks"]
+    if a.dump:
+        import json
+        doc = {"workload": "c3: 512^3 terrain, 1920x1080, GI, pitch -0.5, one sample of every pixel of the sampled tiles",
+               "tiles": len(tiles), "band": a.band,
+               "stages": {names[i]: {"header": int(stage_blocks[i][0]), "descend": int(stage_blocks[i][1]),
+                                     "advance": int(stage_blocks[i][2]), "pop": int(stage_blocks[i][3]),
+                                     "lane_iterations": int(lane_iters[i])} for i in range(4)},
+               "note": "times each block of the walk loop (csrc/vrc_walk.h) is issued by a wave, summed over the sampled tiles: a "
+                       "block is issued when any of the wave's 64 lanes needs it; from the oracle's per-iteration op traces "
+                       "(tests/tools/path_schedule.py --dump)"}
+        json.dump(doc, open(a.dump, "w"), indent=1)
     base = tot["now (pop whenever a lane needs it)"]
     print(f"{len(tiles)} tiles; issued VALU instructions per tile-sample and stage (rounds in brackets)")
     for k in policies:

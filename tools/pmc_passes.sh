@@ -5,10 +5,13 @@ TAG=$1; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/pmc_$TAG
 mkdir -p $OUT
+# (the profiler starts the HIP runtime before bench.py can set this: set it here so that profiled and timed runs map
+# their streams onto hardware queues the same way)
+export GPU_MAX_HW_QUEUES=8
 cd /tmp && export TMPDIR=/tmp
 run() { # name counters...
   local name=$1; shift
-  timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline "${BENCH_ARGS[@]}" > $OUT/$name.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras "${BENCH_ARGS[@]}" > $OUT/$name.log 2>&1
 }
 BENCH_ARGS=("$@")
 run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_THREAD_CYCLES_VALU

@@ -6,9 +6,12 @@ TAG=$1; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/traffic_$TAG
 mkdir -p $OUT
+# (the profiler starts the HIP runtime before bench.py can set this: set it here so that profiled and timed runs map
+# their streams onto hardware queues the same way)
+export GPU_MAX_HW_QUEUES=8
 cd /tmp && export TMPDIR=/tmp
 run() { local name=$1; shift
-  timeout 400 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline "${BENCH_ARGS[@]}" > $OUT/$name.log 2>&1; }
+  timeout 400 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras "${BENCH_ARGS[@]}" > $OUT/$name.log 2>&1; }
 BENCH_ARGS=("$@")
 run fetch FETCH_SIZE
 run write WRITE_SIZE

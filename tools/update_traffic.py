@@ -22,10 +22,24 @@ sys.path.insert(0, ROOT)
 def main():
     src, key, dst_prefix = sys.argv[1], sys.argv[2], sys.argv[3]
     vals = {}
+    kernel_symbol = None
     for line in open(os.path.join(src, "summary.txt")):
         f = line.split()
+        if len(f) == 3 and f[0] == "==" and f[1] == "kernel":
+            if kernel_symbol is not None:
+                break                                             # only the first block: the kernel with the most launches
+            kernel_symbol = f[2]
         if len(f) >= 5 and f[1] == "launches":
             vals[f[0]] = float(f[10]) if len(f) >= 11 and f[9] == "median" else float(f[4])
+    # the settings of the profiled bench command (its JSON line, kept by tools/pmc_roofline.sh)
+    settings = {}
+    log = os.path.join(src, "stats.log")
+    if os.path.exists(log):
+        lines = [ln for ln in open(log).read().splitlines() if ln.startswith("{")]
+        if lines:
+            d = json.loads(lines[-1])
+            settings = {"frames_in_flight": d["config"].get("frames_in_flight"), "fused": d["config"].get("resolve_fused_into_frame_kernel"),
+                        "whole_spp_work_units": d["config"].get("whole_spp_work_units"), "bench_kernel": d["roofline"].get("kernel")}
     source_hash = open(os.path.join(src, "source_hash.txt")).read().strip()
     import bench
     commit = None
@@ -40,7 +54,7 @@ def main():
     ks = os.path.join(src, "kernel_stats.csv")
     if os.path.exists(ks):
         for r in csv.DictReader(open(ks)):
-            if r.get("Name", "").startswith("k_render"):
+            if r.get("Name", "") == kernel_symbol or (kernel_symbol is None and r.get("Name", "").startswith("k_render")):
                 kernel_ms = float(r["AverageNs"]) / 1e6
     fetch = 2.0 * vals["FETCH_SIZE"] * 1024.0
     write = vals["WRITE_SIZE"] * 1024.0
@@ -52,7 +66,11 @@ def main():
         "wait_inst_any_frac_of_wave_cycles": round(vals["SQ_WAIT_INST_ANY"] / vals["SQ_WAVE_CYCLES"], 4),
         "profiled_kernel_ms": round(kernel_ms, 4) if kernel_ms else None,
         "source_hash": source_hash, "commit": commit, "profile": dst_prefix + "_pmc.txt",
+        "kernel": kernel_symbol, "settings": settings,
     }
+    for extra in ("SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_BRANCH", "SQ_WAVES"):
+        if extra in vals:
+            rec[extra.lower()] = int(vals[extra])
     os.makedirs(os.path.dirname(os.path.join(ROOT, dst_prefix)), exist_ok=True)
     shutil.copy(os.path.join(src, "summary.txt"), os.path.join(ROOT, dst_prefix + "_pmc.txt"))
     if os.path.exists(ks):
