@@ -1,0 +1,103 @@
+"""The benchmark's own step, held to the oracle at full size (round-2 verdict, "weak" 5): what bench.py's timed region
+does -- BASELINE config 3: 512^3 FastNoise terrain generated and built on the GPU, 1920x1080, 4 spp GI; three renderers on
+three streams taking turns, work units of a tile's whole sample set (setSampleChunk(spp)), resolve fused into the frame
+kernel (renderFrameResolved) -- for frames 0..5 issued round-robin with no synchronisation in between, and every frame
+compared with the oracle: the WHOLE resolved image and the ray / loop-iteration / hit / pixel counters, plus the kernel
+symbol that ran (what a rocprofv3 trace of bench.py lists).  The same for config 4 (DOF: the general kernel).
+
+Reference anchors: src/main.cpp:139-158 (the frame: renderRay per pixel-sample, samples_to_image), include/raycaster.hpp:
+67-207, include/camera_controller.hpp:34-54 (thin lens)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+FRAMES, IN_FLIGHT = 6, 3
+
+
+def bench_step_frames(vrc, svo, cam, W, H, spp, depth):
+    """frames 0..FRAMES-1 exactly as bench.py's step() issues them at N = 1 (bench.py: make_renderer, step); every frame also
+    resolves into a buffer of its own, so that frame i is still there when frame i + 3 has reused its renderer"""
+    import torch
+    rcs = []
+    for _ in range(IN_FLIGHT):
+        r = vrc.RayCaster(svo, (W, H))
+        r.setLightPosition(vrc.reference_light(depth))
+        r.use_gi, r.use_samples, r.shadow_samples = True, True, 1
+        r.setSampleChunk(spp)
+        rcs.append(r)
+    streams = [torch.cuda.Stream() for _ in range(IN_FLIGHT)]
+    keep = [torch.zeros(H * W * 4, dtype=torch.uint8, device="cuda") for _ in range(FRAMES)]
+    for r in rcs:
+        r.resetSamples(streams[0].cuda_stream)
+        r.stats(reset=True, stream=streams[0].cuda_stream)
+    torch.cuda.synchronize()
+    for i in range(FRAMES):
+        rc, ts = rcs[i % IN_FLIGHT], streams[i % IN_FLIGHT]
+        with torch.cuda.stream(ts):
+            rc.frame_index = i * spp
+            rc.renderFrameResolved(cam, spp=spp, dst_ptr=keep[i].data_ptr(), stream=ts.cuda_stream)
+    torch.cuda.synchronize()
+    images = [k.cpu().numpy().reshape(H, W, 4) for k in keep]
+    stats = [r.stats() for r in rcs]
+    kernels = [r.lastKernel() for r in rcs]
+    last_images = [r.readImage() for r in rcs]                  # frames 3, 4, 5 as the renderers hold them
+    accums_clear = [not r.readAccum().any() for r in rcs]
+    return images, stats, kernels, last_images, accums_clear
+
+
+def oracle_frames(nodes, depth, textures, cam, W, H, spp):
+    import cpuvoxelraycaster_amd as vrc
+    top, side = textures
+    ocam = O.make_camera(tuple(cam.position), tuple(cam.rot), cam.fov, cam.aperture, cam.focal_length)
+    threads = min(64, os.cpu_count() or 8)
+    out = []
+    for f in range(FRAMES):
+        acc = None
+        rays = steps = hits = 0
+        for s in range(spp):
+            p = O.make_params(W, H, vrc.reference_light(depth), use_gi=1, use_samples=1, shadow_samples=1, frame_index=f * spp + s)
+            _, acc, _, st = O.render_frame(nodes, depth, top, side, ocam, p, accum=acc, threads=threads)
+            rays, steps, hits = rays + st.rays, steps + st.sum_complexity, hits + st.primary_hits
+        out.append((O.samples_to_image(acc), rays, steps, hits))
+    return out
+
+
+def check(vrc, svo, nodes, textures, cam, W, H, spp, depth, kernel):
+    images, stats, kernels, last_images, accums_clear = bench_step_frames(vrc, svo, cam, W, H, spp, depth)
+    assert kernels == [kernel] * IN_FLIGHT
+    ref = oracle_frames(nodes, depth, textures, cam, W, H, spp)
+    for f in range(FRAMES):
+        assert np.array_equal(images[f], ref[f][0]), f"frame {f}"
+    for k in range(IN_FLIGHT):                                 # renderer k rendered frames k and k + 3
+        mine = [ref[f] for f in range(FRAMES) if f % IN_FLIGHT == k]
+        st = stats[k]
+        assert (st.rays, st.sum_complexity, st.primary_hits) == tuple(sum(m[j] for m in mine) for j in (1, 2, 3)), k
+        assert st.pixels == W * H * spp * len(mine)
+        assert np.array_equal(last_images[k], images[FRAMES - IN_FLIGHT + k])
+    assert all(accums_clear)                                   # the fused resolve leaves resetSamples' zeros
+
+
+def test_bench_step_c3_pinhole(built, heights, textures):
+    """bench.py default command (config c3): k_render_sync_pinhole_resolved_w8"""
+    import cpuvoxelraycaster_amd as vrc
+    depth, W, H, spp = 9, 1920, 1080, 4
+    svo = vrc.LSVO.fromFastNoiseTerrain(depth, seed=1337, textures=textures)
+    nodes = svo.downloadNodes()
+    assert nodes.tobytes() == vrc.build_terrain_lsvo(heights, depth).tobytes()
+    cam = vrc.reference_camera(depth, pitch=-0.5)
+    check(vrc, svo, nodes, textures, cam, W, H, spp, depth, "k_render_sync_pinhole_resolved_w8")
+
+
+def test_bench_step_c4_dof(built, heights, textures):
+    """bench.py --config c4 (aperture 0.5, focal length 60 voxels as bench.py sets it): k_render_sync_resolved_w8"""
+    import cpuvoxelraycaster_amd as vrc
+    depth, W, H, spp = 9, 1920, 1080, 4
+    svo = vrc.LSVO.fromFastNoiseTerrain(depth, seed=1337, textures=textures)
+    nodes = svo.downloadNodes()
+    cam = vrc.reference_camera(depth, pitch=-0.5, aperture=0.5, focal_length=60.0 * (1 << depth) / 512.0)
+    check(vrc, svo, nodes, textures, cam, W, H, spp, depth, "k_render_sync_resolved_w8")
