@@ -238,10 +238,11 @@ def main():
     ap.add_argument("--inflight", type=int, default=0,
                     help="frames in flight per GPU (renderers / streams used round-robin); 1 = one stream, each frame starts "
                          "when the previous one has ended; 0 = default: 3")
-    ap.add_argument("--gather", default="all", choices=["all", "root"],
+    ap.add_argument("--gather", default="all", choices=["all", "root", "peer"],
                     help="N > 1: how the RGBA8 row-block shards meet: 'all' = RCCL all-gather (every rank ends up with the "
                          "frame), 'root' = RCCL gather to rank 0, the presenting rank (north_star / SURVEY 8e: 1/N of the "
-                         "bytes on the wire)")
+                         "bytes on the wire), 'peer' = no collective: every rank's frame kernel writes its rows straight into "
+                         "rank 0's framebuffer (hipIpc mapping over xGMI, interprocess events; SURVEY 8e 'direct peer writes')")
     ap.add_argument("--fused", default="auto", choices=["auto", "0", "1"],
                     help="resolve + pack + reset inside the frame kernel (vrc_render_frame_resolved) instead of a second kernel; "
                          "auto = whenever frames overlap (whole-spp work units: the fused path then resolves from registers, "
@@ -351,6 +352,11 @@ def main():
 
     ev_pairs = []
     state = {"i": 0, "pending": [None] * n_slots, "last_slot": 0, "gather": args.gather}
+    peers = None
+    if dist_on and args.gather == "peer":
+        # rank 0's F renderers own the framebuffers; the other ranks' renderers write their rows into them
+        # (cpuvoxelraycaster_amd/dist.py PeerFrames: hipIpc-mapped framebuffers, frame flags in shared memory; no collective)
+        peers = vdist.PeerFrames(rcs, local_rank, rank, world, dist.group.WORLD, "/vrc_bench_peer_%s" % os.environ.get("MASTER_PORT", "0"))
 
     def finish_gather(slot):
         """wait (on the current stream) for the slot's outstanding all-gather and scatter it into the slot's frame"""
@@ -375,7 +381,9 @@ def main():
         slot = i % n_slots
         with torch.cuda.stream(ts):
             stream = ts.cuda_stream
-            if dist_on:
+            if peers is not None:
+                peers.before_render(i, stream)                 # rank 0 has consumed the frame this framebuffer held
+            elif dist_on:
                 finish_gather(slot)                            # the frame that used this slot's buffers last
             rc.frame_index = i * spp
             use_ev = timed
@@ -383,7 +391,9 @@ def main():
                 e0 = torch.cuda.Event(enable_timing=True)
                 e1 = torch.cuda.Event(enable_timing=True)
                 e0.record(ts)
-            if dist_on and fused:
+            if peers is not None and fused:
+                rc.renderFrameResolved(cam, spp=spp, stream=stream, row_block=ROW_BLOCK, shard_index=rank, shard_count=world)
+            elif dist_on and fused:
                 rc.renderFrameResolved(cam, spp=spp, dst_ptr=mine[slot].data_ptr(), stream=stream, row_block=ROW_BLOCK, shard_index=rank, shard_count=world)
             elif dist_on:
                 rc.renderFrame(cam, spp=spp, stream=stream, row_block=ROW_BLOCK, shard_index=rank, shard_count=world)
@@ -393,7 +403,13 @@ def main():
                 rc.renderFrame(cam, spp=spp, stream=stream)
             if use_ev:
                 e1.record(ts)
-            if dist_on:
+            if peers is not None:
+                if not fused:
+                    rc.resolveShard(ROW_BLOCK, rank, world, None, reset=True, stream=stream)
+                peers.after_render(i, stream)                  # rank 0: the frame is complete on this stream after the call
+                peers.consumed_on(i, stream)                   # (nothing reads it here: a presenter would, before this line)
+                state["last_slot"] = i % F
+            elif dist_on:
                 if not fused:                                      # (fused: resolved, packed and reset by the frame kernel)
                     rc.resolveShard(ROW_BLOCK, rank, world, mine[slot].data_ptr(), reset=True, stream=stream)
                 if backend == "nccl":
@@ -415,7 +431,7 @@ def main():
             ev_pairs.append((e0, e1))
 
     def drain():
-        if dist_on:
+        if dist_on and peers is None:
             torch.cuda.synchronize()                           # every frame stream has produced its shard
             for k in range(n_slots):
                 finish_gather((state["i"] + k) % n_slots)      # oldest first; on the current stream
@@ -498,12 +514,13 @@ def main():
         ref.renderFrame(cam, spp=spp, stream=stream)
         ref.samples_to_image(stream)
         torch.cuda.synchronize()
-        verified = bool(np.array_equal(full[state["last_slot"]].cpu().numpy().reshape(H, W, 4), ref.readImage(stream)))
+        got = rcs[state["last_slot"]].readImage(stream) if peers is not None else full[state["last_slot"]].cpu().numpy().reshape(H, W, 4)
+        verified = bool(np.array_equal(got, ref.readImage(stream)))
 
     # extra, N > 1 on RCCL: the same frames with the OTHER exchange form (all-gather <-> gather to rank 0), so that one
     # driver run records both (not part of `value`)
     other = None
-    if dist_on and backend == "nccl":
+    if dist_on and backend == "nccl" and peers is None:
         try:
             state["gather"] = "root" if args.gather == "all" else "all"
             n_o = max(5, min(args.steps, 30))
@@ -747,7 +764,8 @@ def main():
                        "camera_pitch": args.pitch, "lsvo_nodes": svo.n_nodes,
                        "lsvo_gpu_build_ms": round(svo.build_ms, 3), "lsvo_gpu_build_call_ms": round(build_call_ms, 3),
                        "frames_in_flight": F, "whole_spp_work_units": whole_spp_units, "resolve_fused_into_frame_kernel": fused, "host_enqueue_us_per_step": round(host_enqueue_us, 1), "sharding": f"{ROW_BLOCK}-row blocks round-robin over {world} GPU(s)"
-                       + (f", RCCL {'gather to rank 0' if args.gather == 'root' else 'all-gather'} of RGBA8 shards" if dist_on else ""),
+                       + ((", direct peer writes into rank 0's framebuffers (hipIpc), no collective" if args.gather == "peer" else
+                          f", RCCL {'gather to rank 0' if args.gather == 'root' else 'all-gather'} of RGBA8 shards") if dist_on else ""),
                        "ranks_in_process_group": (dist.get_world_size() if dist_on else 1),
                        "gathered_frame_equals_unsharded": verified},
             "roofline": roof,
@@ -764,6 +782,10 @@ def main():
             out["extra"] = extras
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, svo.downloadNodes(), textures, cam, light)
+    if dist_on:
+        dist.barrier()
+    if peers is not None:
+        peers.close()
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()

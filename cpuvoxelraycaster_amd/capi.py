@@ -104,6 +104,15 @@ SYMBOLS = {
     "vrc_renderer_set_sample_chunk": (_int, [_vp, _u32]),
     "vrc_renderer_set_invariant_ray_reuse": (_int, [_vp, _u32]),
     "vrc_renderer_last_kernel": (C.c_char_p, [_vp]),
+    "vrc_ipc_export_image": (_int, [_vp, _vp]),
+    "vrc_ipc_open_image": (_int, [_int, _vp, C.POINTER(_vp)]),
+    "vrc_ipc_close_image": (_int, [_int, _vp]),
+    "vrc_renderer_set_image_target": (_int, [_vp, _vp]),
+    "vrc_ipc_flags_open": (_int, [C.c_char_p, _u32, _int, _int, C.POINTER(_vp)]),
+    "vrc_ipc_flags_close": (_int, [_vp]),
+    "vrc_stream_write_flag": (_int, [_vp, _u32, _u32, _vp]),
+    "vrc_stream_wait_flag": (_int, [_vp, _u32, _u32, _vp]),
+    "vrc_ipc_flag_value": (_u32, [_vp, _u32]),
     "vrc_stream_create": (_int, [_int, C.POINTER(_vp)]),
     "vrc_stream_destroy": (_int, [_int, _vp]),
     "vrc_stream_synchronize": (_int, [_int, _vp]),
@@ -145,6 +154,8 @@ def ptr(a):
         return None
     if isinstance(a, np.ndarray):
         return a.ctypes.data_as(C.c_void_p)
+    if isinstance(a, C.c_void_p):
+        return a
     return C.c_void_p(int(a))  # raw device pointer (e.g. torch tensor .data_ptr())
 
 

@@ -16,6 +16,12 @@
 #include <vector>
 #include "vrc_internal.h"
 
+#include <errno.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 namespace {
 thread_local char g_err[512] = "";
 }
@@ -96,6 +102,7 @@ struct vrc_renderer {
     int device = 0;
     uint32_t width = 0, height = 0;
     void* d_image = nullptr;  // RGBA8
+    void* image_target = nullptr;   // where sharded frames are resolved to instead of d_image (vrc_renderer_set_image_target): a peer's framebuffer
     void* d_accum = nullptr;  // 4 x u32 per pixel
     void* d_stats = nullptr;  // VRC_STATS_BYTES of counter slots, then VRC_QUEUE_BYTES of work-queue heads
     vrc_hit* d_prim = nullptr;
@@ -547,7 +554,8 @@ int render_impl(vrc_renderer* r, const vrc_camera* cam, const vrc_frame_params* 
     memset(&a, 0, sizeof(a));
     a.nodes = (const uint2*)s->d_nodes;
     a.tex = (const uint8_t*)s->d_tex;
-    a.image = (uint8_t*)r->d_image;
+    // a sample-mode frame of a shard may be resolved straight into another renderer's framebuffer (direct peer writes)
+    a.image = (uint8_t*)((fused && r->image_target) ? r->image_target : r->d_image);
     a.accum = (uint32_t*)r->d_accum;
     a.prim = r->d_prim;
     a.stats = (uint64_t*)r->d_stats;
@@ -681,6 +689,130 @@ extern "C" int vrc_clear_image(vrc_renderer* r, void* stream)
     return VRC_OK;
 }
 
+// ---- direct peer writes ("... or direct peer writes into the root's framebuffer") ----
+// The presenting rank exports its renderer's framebuffer; every other rank opens it and makes it the target of its own
+// renderer, whose frame kernel then writes this rank's rows of the frame where they belong: no pack, no collective, no
+// unpack.  Ordering across processes is by interprocess events (one per frame slot and direction).
+static_assert(sizeof(hipIpcMemHandle_t) <= sizeof(vrc_ipc_handle), "vrc_ipc_handle too small for hipIpcMemHandle_t");
+
+extern "C" int vrc_ipc_export_image(vrc_renderer* r, vrc_ipc_handle* out)
+{
+    if (!r || !out) return fail(VRC_ERR_INVALID, "vrc_ipc_export_image: null argument");
+    HIP_TRY(hipSetDevice(r->device));
+    memset(out, 0, sizeof(*out));
+    hipIpcMemHandle_t h;
+    HIP_TRY(hipIpcGetMemHandle(&h, r->d_image));
+    memcpy(out, &h, sizeof(h));
+    return VRC_OK;
+}
+
+extern "C" int vrc_ipc_open_image(int device, const vrc_ipc_handle* handle, void** image_dev)
+{
+    if (!handle || !image_dev) return fail(VRC_ERR_INVALID, "vrc_ipc_open_image: null argument");
+    int rc = vrc::require_device(device, nullptr);
+    if (rc) return rc;
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle, sizeof(h));
+    HIP_TRY(hipIpcOpenMemHandle(image_dev, h, hipIpcMemLazyEnablePeerAccess));
+    return VRC_OK;
+}
+
+extern "C" int vrc_ipc_close_image(int device, void* image_dev)
+{
+    if (!image_dev) return VRC_OK;
+    int rc = vrc::require_device(device, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipIpcCloseMemHandle(image_dev));
+    return VRC_OK;
+}
+
+extern "C" int vrc_renderer_set_image_target(vrc_renderer* r, void* image_dev)
+{
+    if (!r) return fail(VRC_ERR_INVALID, "null renderer");
+    r->image_target = image_dev;
+    return VRC_OK;
+}
+
+// Frame flags shared by the processes of a node: 32-bit counters in a POSIX shared-memory segment that every process maps
+// and registers with its HIP runtime, written and waited for IN STREAM ORDER (hipStreamWriteValue32 / hipStreamWaitValue32,
+// greater-or-equal): "rank k's rows of frame n are in framebuffer s", "framebuffer s has been consumed up to frame n".  A
+// wait names a VALUE, not an earlier call, so the processes need no host messages to keep their calls in order (interprocess
+// HIP events would: a wait refers to the last record the waiting process has seen -- and ROCm 7.2's lose count after 32
+// records per event).
+struct vrc_ipc_flags {
+    int device = 0;
+    uint32_t count = 0;
+    size_t bytes = 0;
+    uint32_t* host = nullptr;     // the mapping
+    uint32_t* dev = nullptr;      // the same words as the device sees them
+    bool owner = false;
+    char name[96] = {0};
+};
+
+extern "C" int vrc_ipc_flags_open(const char* name, uint32_t count, int device, int create, vrc_ipc_flags** out)
+{
+    if (!name || !out || !count || count > (1u << 20)) return fail(VRC_ERR_INVALID, "vrc_ipc_flags_open: bad argument");
+    if (name[0] != '/' || strlen(name) >= sizeof(vrc_ipc_flags::name)) return fail(VRC_ERR_INVALID, "vrc_ipc_flags_open: name must be \"/something\" (shm_open)");
+    int rc = vrc::require_device(device, nullptr);
+    if (rc) return rc;
+    const size_t page = 4096, bytes = (((size_t)count * 4u) + page - 1) / page * page;
+    int fd = create ? shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600) : shm_open(name, O_RDWR, 0600);
+    if (fd < 0) return fail(VRC_ERR_INVALID, "vrc_ipc_flags_open: shm_open(%s): %s", name, strerror(errno));
+    if (create && ftruncate(fd, (off_t)bytes) != 0) {           // a new segment reads as zeros
+        const int e = errno; close(fd); shm_unlink(name);
+        return fail(VRC_ERR_INVALID, "vrc_ipc_flags_open: ftruncate: %s", strerror(e));
+    }
+    void* m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    const int em = errno;
+    close(fd);
+    if (m == MAP_FAILED) { if (create) shm_unlink(name); return fail(VRC_ERR_INVALID, "vrc_ipc_flags_open: mmap: %s", strerror(em)); }
+    hipError_t e = hipHostRegister(m, bytes, hipHostRegisterMapped);
+    void* d = nullptr;
+    if (e == hipSuccess) e = hipHostGetDevicePointer(&d, m, 0);
+    if (e != hipSuccess) {
+        munmap(m, bytes);
+        if (create) shm_unlink(name);
+        return fail(VRC_ERR_HIP, "vrc_ipc_flags_open: registering the segment: %s", hipGetErrorString(e));
+    }
+    vrc_ipc_flags* f = new vrc_ipc_flags;
+    f->device = device; f->count = count; f->bytes = bytes; f->host = (uint32_t*)m; f->dev = (uint32_t*)d; f->owner = create != 0;
+    snprintf(f->name, sizeof(f->name), "%s", name);
+    *out = f;
+    return VRC_OK;
+}
+
+extern "C" int vrc_ipc_flags_close(vrc_ipc_flags* f)
+{
+    if (!f) return VRC_OK;
+    (void)hipSetDevice(f->device);
+    (void)hipHostUnregister(f->host);
+    munmap(f->host, f->bytes);
+    if (f->owner) shm_unlink(f->name);
+    delete f;
+    return VRC_OK;
+}
+
+extern "C" int vrc_stream_write_flag(vrc_ipc_flags* f, uint32_t index, uint32_t value, void* stream)
+{
+    if (!f || index >= f->count) return fail(VRC_ERR_INVALID, "vrc_stream_write_flag: bad argument");
+    HIP_TRY(hipSetDevice(f->device));
+    HIP_TRY(hipStreamWriteValue32((hipStream_t)stream, f->dev + index, value, 0));
+    return VRC_OK;
+}
+
+extern "C" int vrc_stream_wait_flag(vrc_ipc_flags* f, uint32_t index, uint32_t value, void* stream)
+{
+    if (!f || index >= f->count) return fail(VRC_ERR_INVALID, "vrc_stream_wait_flag: bad argument");
+    HIP_TRY(hipSetDevice(f->device));
+    HIP_TRY(hipStreamWaitValue32((hipStream_t)stream, f->dev + index, value, hipStreamWaitValueGte, 0xffffffffu));
+    return VRC_OK;
+}
+
+extern "C" uint32_t vrc_ipc_flag_value(const vrc_ipc_flags* f, uint32_t index)
+{
+    return (f && index < f->count) ? __atomic_load_n(f->host + index, __ATOMIC_ACQUIRE) : 0u;
+}
+
 extern "C" void* vrc_image_device_ptr(vrc_renderer* r) { return r ? r->d_image : nullptr; }
 extern "C" void* vrc_accum_device_ptr(vrc_renderer* r) { return r ? r->d_accum : nullptr; }
 
@@ -764,7 +896,7 @@ extern "C" int vrc_resolve_shard(vrc_renderer* r, uint32_t row_block, uint32_t s
     if (!row_block) return fail(VRC_ERR_INVALID, "vrc_resolve_shard: row_block is 0");
     HIP_TRY(hipSetDevice(r->device));
     uint32_t* queue = (uint32_t*)((uint8_t*)r->d_stats + vrc::VRC_STATS_BYTES);
-    HIP_TRY(vrc::launch_resolve_shard(r->d_accum, r->d_image, r->width, r->height, row_block, shard_index, shard_count,
+    HIP_TRY(vrc::launch_resolve_shard(r->d_accum, r->image_target ? r->image_target : r->d_image, r->width, r->height, row_block, shard_index, shard_count,
                                       shard_slots(r->height, row_block, shard_count), dst_dev, reset ? 1u : 0u, queue,
                                       (hipStream_t)stream));
     if (reset) r->queue_zero[0] = true;     // k_resolve_shard zeroes the first set's heads in the same pass

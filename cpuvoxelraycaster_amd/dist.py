@@ -78,6 +78,83 @@ def exchange_shards(mine, gathered, world, rank, mode="all", async_op=False):
     return dist.all_gather_into_tensor(gathered, mine, async_op=async_op)
 
 
+class PeerFrames:
+    """The third exchange form (SURVEY 8e "direct peer writes"; bench.py --gather peer): rank 0, the presenting rank, owns the
+    framebuffers -- those of its `renderers` --, exports them (vrc_ipc_export_image), and every other rank's frame kernel
+    writes its rows of frame i straight into rank 0's framebuffer i % F (full-frame layout: no pack, no collective, no unpack).
+
+    Ordering is by frame flags in a shared-memory segment (include/vrc.h: vrc_ipc_flags_open), written and waited for in
+    stream order: written[slot][k] = 1 + the last frame whose rows rank k has put into framebuffer `slot` (rank 0's stream
+    waits for it before the frame is read), consumed[slot] = 1 + the last frame of that framebuffer rank 0 has consumed (the
+    writers' streams wait for it before the next frame goes in).  A wait names a value, so the hosts exchange nothing per
+    frame; the image handles travel once, at set-up, through all_gather_object on `group` (any backend)."""
+
+    def __init__(self, renderers, device, rank, world, group, name):
+        import ctypes as C
+        import torch.distributed as dist
+        from . import capi
+        L = capi.load()
+        self.rank, self.world, self.device = rank, world, device
+        self.renderers = renderers
+        F = self.F = len(renderers)
+        self._flags = C.c_void_p()
+        n = F * world + F                                      # written[slot][rank] then consumed[slot]
+        if rank == 0:
+            capi.check(L.vrc_ipc_flags_open(name.encode(), n, device, 1, C.byref(self._flags)))
+        everyone = [None] * world
+        dist.all_gather_object(everyone, [r.exportImage() for r in renderers] if rank == 0 else None, group=group)
+        self.targets = []
+        if rank != 0:
+            capi.check(L.vrc_ipc_flags_open(name.encode(), n, device, 0, C.byref(self._flags)))
+            for s, r in enumerate(renderers):
+                buf = (C.c_ubyte * 64).from_buffer_copy(everyone[0][s])
+                tgt = C.c_void_p()
+                capi.check(L.vrc_ipc_open_image(device, C.byref(buf), C.byref(tgt)))
+                self.targets.append(tgt)
+                r.setImageTarget(tgt)
+
+    def _written(self, slot, k):
+        return slot * self.world + k
+
+    def _consumed(self, slot):
+        return self.F * self.world + slot
+
+    def before_render(self, frame, stream):
+        """a writer must not touch framebuffer frame % F before rank 0 has consumed frame - F, which it holds"""
+        from . import capi
+        if self.rank != 0 and frame >= self.F:
+            capi.check(capi.load().vrc_stream_wait_flag(self._flags, self._consumed(frame % self.F), frame - self.F + 1, capi.ptr(stream)))
+
+    def after_render(self, frame, stream):
+        """writer: my rows are in.  Rank 0: wait for every writer's rows -- the frame is complete on `stream` after this call"""
+        from . import capi
+        L, slot = capi.load(), frame % self.F
+        if self.rank != 0:
+            capi.check(L.vrc_stream_write_flag(self._flags, self._written(slot, self.rank), frame + 1, capi.ptr(stream)))
+        else:
+            for k in range(1, self.world):
+                capi.check(L.vrc_stream_wait_flag(self._flags, self._written(slot, k), frame + 1, capi.ptr(stream)))
+
+    def consumed_on(self, frame, stream):
+        """rank 0: everything enqueued on `stream` so far has read the frame; writers may reuse its framebuffer after that"""
+        from . import capi
+        if self.rank == 0:
+            capi.check(capi.load().vrc_stream_write_flag(self._flags, self._consumed(frame % self.F), frame + 1, capi.ptr(stream)))
+
+    def close(self):
+        """after every rank has synchronised its streams (the caller's barrier)"""
+        from . import capi
+        for r in self.renderers:
+            if self.rank != 0:
+                r.setImageTarget(None)
+        for t in self.targets:
+            capi.load().vrc_ipc_close_image(self.device, t)
+        self.targets = []
+        if self._flags:
+            capi.load().vrc_ipc_flags_close(self._flags)
+            self._flags = None
+
+
 def reduce_stats(values, device):
     """Sum per-rank counters (rays, loop iterations, pixels) over ranks."""
     import torch

@@ -224,6 +224,18 @@ class RayCaster:
         check(capi.load().vrc_render_frame_resolved(self._h, C.byref(camera), C.byref(p), ptr(dst_ptr), ptr(stream)))
         self.frame_index += spp
 
+    # ---- direct peer writes (include/vrc.h: vrc_ipc_*, vrc_renderer_set_image_target) ----
+    def exportImage(self):
+        """64 opaque bytes naming this renderer's framebuffer for the other processes of the node"""
+        h = (C.c_ubyte * 64)()
+        check(capi.load().vrc_ipc_export_image(self._h, C.byref(h)))
+        return bytes(h)
+
+    def setImageTarget(self, image_dev_ptr):
+        """sharded sample-mode frames are resolved into that framebuffer (full-frame layout) instead of this renderer's own;
+        None = own image again"""
+        check(capi.load().vrc_renderer_set_image_target(self._h, ptr(image_dev_ptr)))
+
     def setPrimaryCapture(self, dev_ptr):
         check(capi.load().vrc_renderer_set_primary_capture(self._h, ptr(dev_ptr)))
 

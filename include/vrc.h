@@ -231,6 +231,30 @@ int vrc_read_accum(vrc_renderer *r, uint32_t *accum_host, void *stream);  /* syn
 /* Synchronises `stream`, returns and optionally clears the running stats. */
 int vrc_get_stats(vrc_renderer *r, vrc_frame_stats *out, int reset, void *stream);
 
+/* Direct peer writes (the alternative to a collective -- "direct peer writes into the root's framebuffer";
+ * include/raycaster.hpp:84,261: the one render_image every swarm worker writes its pixels into).  The presenting process
+ * exports the framebuffer of a renderer (vrc_ipc_export_image); every other process of the node opens it
+ * (vrc_ipc_open_image) and makes it the target of its own renderer (vrc_renderer_set_image_target): a sharded
+ * vrc_render_frame_resolved / vrc_resolve_shard then writes this shard's rows of the frame where they belong in the
+ * presenter's memory -- over xGMI between GPUs -- instead of into the renderer's own image: no pack, no collective, no unpack.
+ * Ordering between the processes is by FRAME FLAGS: 32-bit counters in a POSIX shared-memory segment (vrc_ipc_flags_open:
+ * one process creates "/name", the others open it) that are written and waited for in stream order -- a writer sets "my
+ * rows of frame n are in" behind its frame (vrc_stream_write_flag), the presenter's stream waits until the flag is >= n
+ * (vrc_stream_wait_flag) before it reads the frame, and the other way round before a writer reuses a framebuffer.  A wait
+ * names a value, so no host-side handshake is needed.  The image handle is 64 opaque bytes to pass by any host channel. */
+typedef struct vrc_ipc_handle { unsigned char opaque[64]; } vrc_ipc_handle;
+typedef struct vrc_ipc_flags vrc_ipc_flags;
+int vrc_ipc_export_image(vrc_renderer *r, vrc_ipc_handle *out);
+int vrc_ipc_open_image(int device, const vrc_ipc_handle *handle, void **image_dev);
+int vrc_ipc_close_image(int device, void *image_dev);
+/* image_dev: RGBA8 width x height of this renderer's size on any device this one can reach; NULL = the renderer's own image. */
+int vrc_renderer_set_image_target(vrc_renderer *r, void *image_dev);
+int vrc_ipc_flags_open(const char *name, uint32_t count, int device, int create, vrc_ipc_flags **out);   /* zeros when created */
+int vrc_ipc_flags_close(vrc_ipc_flags *f);                     /* the creator also removes the segment */
+int vrc_stream_write_flag(vrc_ipc_flags *f, uint32_t index, uint32_t value, void *stream);
+int vrc_stream_wait_flag(vrc_ipc_flags *f, uint32_t index, uint32_t value, void *stream);      /* until flag >= value */
+uint32_t vrc_ipc_flag_value(const vrc_ipc_flags *f, uint32_t index);                           /* host read */
+
 /* Multi-GPU frame sharding: compact this shard's row blocks into
  * `dst_dev` (ceil(nblocks/shard_count) blocks of row_block*width*4 bytes), and
  * the inverse scatter of an all-gathered buffer [shard][slot] into a full frame. */

@@ -1,0 +1,54 @@
+"""Direct peer writes (round-2 verdict item 4): two processes on ONE GPU, each rendering its row blocks of the
+frame; rank 1's frame kernel writes its rows straight into rank 0's framebuffer through an hipIpc mapping
+(vrc_ipc_export_image / vrc_ipc_open_image / vrc_renderer_set_image_target), ordered by frame flags in shared memory.  Three frames in
+flight, nine consecutive frames (every framebuffer reused twice): each composed frame must equal the unsharded render bit for
+bit.  The multi-GPU form of the same code is bench.py --gather peer."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_peer_written_frames_equal_unsharded(built, world):
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "peer_write_worker.py")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=40)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            tails = [q.communicate()[1][-600:] for q in procs]
+            raise AssertionError("peer-write workers timed out:\n" + "\n---\n".join(tails))
+        outs.append((p.returncode, o, e))
+    assert all(rc == 0 for rc, _, _ in outs), "\n".join(f"--- rank {k} rc {rc}\n{e[-2500:]}" for k, (rc, _, e) in enumerate(outs))
+    line = [ln for ln in outs[0][1].splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["frames"] == 9 and d["frames_in_flight"] == 3 and d["world"] == world
+    assert d["composed_frame_equals_unsharded"] == [True] * 9, d
+    log = os.path.join(ROOT, "gpurun_out", "r03")
+    os.makedirs(log, exist_ok=True)
+    with open(os.path.join(log, f"peer_write_world{world}.json.log"), "w") as f:
+        f.write(line + "\n")
