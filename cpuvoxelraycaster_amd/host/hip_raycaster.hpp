@@ -92,6 +92,13 @@ public:
     {
         check(vrc_scene_create(lnodes, n_nodes, depth, device, &scene_), "vrc_scene_create");
     }
+    // main.cpp:59-88 on the device: FastNoise heights (seed as main.cpp:61) -> voxels -> LSVO, straight into HBM
+    static std::unique_ptr<HipLSVO> fromFastNoiseTerrain(int32_t seed, uint32_t depth, int device = 0, float* build_ms = nullptr)
+    {
+        vrc_scene* s = nullptr;
+        check(vrc_scene_build_fastnoise_terrain(seed, depth, device, &s, build_ms), "vrc_scene_build_fastnoise_terrain");
+        return std::unique_ptr<HipLSVO>(new HipLSVO(s));
+    }
     ~HipLSVO() { vrc_scene_destroy(scene_); }
     HipLSVO(const HipLSVO&) = delete;
     HipLSVO& operator=(const HipLSVO&) = delete;
@@ -151,6 +158,7 @@ private:
         p.complexity = h.complexity;
         return p;
     }
+    explicit HipLSVO(vrc_scene* adopted) : scene_(adopted) {}
     vrc_scene* scene_ = nullptr;
 };
 
@@ -250,6 +258,11 @@ public:
         check(vrc_get_stats(r_, &s, reset ? 1 : 0, nullptr), "vrc_get_stats");
         return s;
     }
+
+    // Direct peer writes: the presenting process exports its framebuffer, the others resolve
+    // their shards of the frame straight into it
+    vrc_ipc_handle exportImage() const { vrc_ipc_handle h; check(vrc_ipc_export_image(r_, &h), "vrc_ipc_export_image"); return h; }
+    void setImageTarget(void* image_dev) { check(vrc_renderer_set_image_target(r_, image_dev), "vrc_renderer_set_image_target"); }
 
     vrc_renderer* handle() const { return r_; }
     // sample counter of the next frame (the RNG key: frame_index + sample); renderFrame* advance it by spp
