@@ -29,7 +29,9 @@
 //
 // Register plan: ds_read_b64 / ds_write_b64 move the stack entry {parent_id, t_max} as one register pair and the node load
 // returns a pair; inline asm cannot name the halves of a 64-bit operand, so those four live in fixed registers (v42:43,
-// v46:47); everything else is allocated by the compiler.  Every read-write operand is early-clobber ("+&v"): without it the
+// v46:47); everything else is allocated by the compiler.  Seven scratch registers serve all four blocks (the kernels are at
+// their register budget): `kind`, the result, is child_shift inside the loop; descend computes its half-points in m, t, t2
+// once the header is done with them; the advance keeps its steps in kind, m, t2 for the pop.  Every read-write operand is early-clobber ("+&v"): without it the
 // compiler may give an INPUT that happens to hold the same value (coef = 0.5 and the initial scale_f = 0.5) the same register,
 // and the loop then changes the input under its own feet.
 #pragma once
@@ -101,12 +103,12 @@ __device__ __forceinline__ walk_rsrc_t walk_node_rsrc(const uint2* __restrict__ 
     "s_add_u32 %[siter], %[siter], 1\n"                                                         \
     "s_cbranch_scc1 Lwalk_done%=\n"             /* safety net */                                \
     COUNTPART                                   /* :73 ++complexity */                          \
-    "v_xor_b32_e32 %[cs], %[co], %[mirror]\n"   /* :79 child_shift */                           \
+    "v_xor_b32_e32 %[kind], %[co], %[mirror]\n"   /* :79 child_shift */                           \
     "v_mul_f32_e32 %[cx], %[px], %[tcx]\n"      /* :76 */                                       \
     "v_mul_f32_e32 %[cy], %[py], %[tcy]\n"                                                      \
     "v_mul_f32_e32 %[cz], %[pz], %[tcz]\n"                                                      \
     "s_waitcnt vmcnt(0)\n"                      /* node of the current parent */                \
-    "v_lshrrev_b32_e32 %[m], %[cs], v46\n"      /* bit 8: child, bit 16: leaf */                \
+    "v_lshrrev_b32_e32 %[m], %[kind], v46\n"      /* bit 8: child, bit 16: leaf */                \
     "v_sub_f32_e32 %[cx], %[cx], %[tox]\n"                                                      \
     "v_sub_f32_e32 %[cy], %[cy], %[toy]\n"                                                      \
     "v_sub_f32_e32 %[cz], %[cz], %[toz]\n"                                                      \
@@ -126,33 +128,34 @@ __device__ __forceinline__ walk_rsrc_t walk_node_rsrc(const uint2* __restrict__ 
        ray); h is not kept at all */                                                            \
     "ds_write_b64 %[sp], v[42:43]\n"                                                            \
     "v_mul_f32_e32 %[sf], 0.5, %[sf]\n"         /* :87 half, becomes scale_f :105 */            \
-    "v_add3_u32 v42, v42, v47, %[cs]\n"         /* :103 */                                      \
+    "v_add3_u32 v42, v42, v47, %[kind]\n"         /* :103 */                                      \
     VRC_WALK_LOAD_NODE                                                                          \
-    "v_mul_f32_e32 %[hx], %[tcx], %[sf]\n"      /* :88 half * t_coef + c */                     \
-    "v_mul_f32_e32 %[hy], %[tcy], %[sf]\n"                                                      \
-    "v_mul_f32_e32 %[hz], %[tcz], %[sf]\n"                                                      \
-    "v_add_f32_e32 %[hx], %[hx], %[cx]\n"                                                       \
-    "v_add_f32_e32 %[hy], %[hy], %[cy]\n"                                                       \
-    "v_add_f32_e32 %[hz], %[hz], %[cz]\n"                                                       \
-    TMAXPART                                    /* :110 t_max = tv_max */                       \
+    TMAXPART                                    /* :110 t_max = tv_max (t2 is free after it) */ \
+    /* h = half * t_coef + c (:88) in the header's scratch registers: m, t, t2 */               \
+    "v_mul_f32_e32 %[m], %[tcx], %[sf]\n"                                                       \
+    "v_mul_f32_e32 %[t], %[tcy], %[sf]\n"                                                       \
+    "v_mul_f32_e32 %[t2], %[tcz], %[sf]\n"                                                      \
+    "v_add_f32_e32 %[m], %[m], %[cx]\n"                                                         \
+    "v_add_f32_e32 %[t], %[t], %[cy]\n"                                                         \
+    "v_add_f32_e32 %[t2], %[t2], %[cz]\n"                                                       \
     /* :107-109 without compares: th > t_min is the sign of t_min - th (never -0: t_min >= +0; never NaN: both finite); \
-       as a mask it selects scale_f for the float add the reference does, and the child bit */                       \
-    "v_sub_f32_e32 %[hx], %[tmin], %[hx]\n"                                                     \
-    "v_sub_f32_e32 %[hy], %[tmin], %[hy]\n"                                                     \
-    "v_sub_f32_e32 %[hz], %[tmin], %[hz]\n"                                                     \
+       as a mask it gives the child bit and selects scale_f for the float add the reference does */                  \
+    "v_sub_f32_e32 %[m], %[tmin], %[m]\n"                                                       \
+    "v_sub_f32_e32 %[t], %[tmin], %[t]\n"                                                       \
+    "v_sub_f32_e32 %[t2], %[tmin], %[t2]\n"                                                     \
     "v_add_u32_e32 %[sp], 0xfffff800, %[sp]\n"  /* :104 --scale: the next stack row down */     \
-    "v_ashrrev_i32_e32 %[hx], 31, %[hx]\n"                                                      \
-    "v_ashrrev_i32_e32 %[hy], 31, %[hy]\n"                                                      \
-    "v_ashrrev_i32_e32 %[hz], 31, %[hz]\n"                                                      \
-    "v_and_b32_e32 %[t], %[sf], %[hx]\n"                                                        \
-    "v_and_b32_e32 %[t2], %[sf], %[hy]\n"                                                       \
-    "v_and_b32_e32 %[m], %[sf], %[hz]\n"                                                        \
-    "v_add_f32_e32 %[px], %[px], %[t]\n"        /* exact: pos is a multiple of 2 * half */      \
-    "v_add_f32_e32 %[py], %[py], %[t2]\n"                                                       \
-    "v_add_f32_e32 %[pz], %[pz], %[m]\n"                                                        \
-    "v_and_b32_e32 %[co], 1, %[hx]\n"                                                           \
-    "v_and_or_b32 %[co], %[hy], 2, %[co]\n"                                                     \
-    "v_and_or_b32 %[co], %[hz], 4, %[co]\n"                                                     \
+    "v_ashrrev_i32_e32 %[m], 31, %[m]\n"                                                        \
+    "v_ashrrev_i32_e32 %[t], 31, %[t]\n"                                                        \
+    "v_ashrrev_i32_e32 %[t2], 31, %[t2]\n"                                                      \
+    "v_and_b32_e32 %[co], 1, %[m]\n"                                                            \
+    "v_and_or_b32 %[co], %[t], 2, %[co]\n"                                                      \
+    "v_and_or_b32 %[co], %[t2], 4, %[co]\n"                                                     \
+    "v_and_b32_e32 %[m], %[sf], %[m]\n"                                                         \
+    "v_and_b32_e32 %[t], %[sf], %[t]\n"                                                         \
+    "v_and_b32_e32 %[t2], %[sf], %[t2]\n"                                                       \
+    "v_add_f32_e32 %[px], %[px], %[m]\n"        /* exact: pos is a multiple of 2 * half */      \
+    "v_add_f32_e32 %[py], %[py], %[t]\n"                                                        \
+    "v_add_f32_e32 %[pz], %[pz], %[t2]\n"                                                       \
     /* ---- advance :113-122 ---- */                                                            \
     "Lwalk_adv%=:\n"                                                                            \
     "s_andn2_b64 exec, %[srun], %[sin]\n"                                                       \
@@ -162,22 +165,22 @@ __device__ __forceinline__ walk_rsrc_t walk_node_rsrc(const uint2* __restrict__ 
     "v_cmp_le_f32_e32 vcc, %[cz], %[tc]\n"                                                      \
     "v_mov_b32_e32 %[tmin], %[tc]\n"            /* :120 */                                      \
     "v_cndmask_b32_e64 %[normal], 0, 1, vcc\n"                                                  \
-    "v_cndmask_b32_e64 %[hx], 0, %[sf], %[sx]\n"                                                \
+    "v_cndmask_b32_e64 %[kind], 0, %[sf], %[sx]\n"                                                \
     "v_addc_co_u32_e64 %[normal], %[st], %[normal], %[normal], %[sy]\n"                         \
-    "v_cndmask_b32_e64 %[hy], 0, %[sf], %[sy]\n"                                                \
-    "v_cndmask_b32_e32 %[hz], 0, %[sf], vcc\n"                                                  \
+    "v_cndmask_b32_e64 %[m], 0, %[sf], %[sy]\n"                                                \
+    "v_cndmask_b32_e32 %[t2], 0, %[sf], vcc\n"                                                  \
     "v_addc_co_u32_e64 %[normal], %[st], %[normal], %[normal], %[sx]\n"   /* :122 */            \
-    "v_sub_f32_e32 %[px], %[px], %[hx]\n"                                                       \
-    "v_sub_f32_e32 %[py], %[py], %[hy]\n"                                                       \
-    "v_sub_f32_e32 %[pz], %[pz], %[hz]\n"                                                       \
+    "v_sub_f32_e32 %[px], %[px], %[kind]\n"                                                       \
+    "v_sub_f32_e32 %[py], %[py], %[m]\n"                                                       \
+    "v_sub_f32_e32 %[pz], %[pz], %[t2]\n"                                                       \
     "v_xor_b32_e32 %[co], %[co], %[normal]\n"   /* :121 */                                      \
     "v_and_b32_e32 %[t], %[co], %[normal]\n"                                                    \
     "v_cmpx_ne_u32_e32 vcc, 0, %[t]\n"          /* :124 */                                      \
     "s_cbranch_execz Lwalk_next%=\n"                                                            \
     /* ---- pop :125-145 ---- */                                                                \
-    "v_add_f32_e32 %[cx], %[px], %[hx]\n"       /* pos before the step (exact) */               \
-    "v_add_f32_e32 %[cy], %[py], %[hy]\n"                                                       \
-    "v_add_f32_e32 %[cz], %[pz], %[hz]\n"                                                       \
+    "v_add_f32_e32 %[cx], %[px], %[kind]\n"       /* pos before the step (exact) */               \
+    "v_add_f32_e32 %[cy], %[py], %[m]\n"                                                       \
+    "v_add_f32_e32 %[cz], %[pz], %[t2]\n"                                                       \
     "v_xor_b32_e32 %[cx], %[cx], %[px]\n"                                                       \
     "v_xor_b32_e32 %[cy], %[cy], %[py]\n"                                                       \
     "v_xor_b32_e32 %[cz], %[cz], %[pz]\n"                                                       \
@@ -191,7 +194,7 @@ __device__ __forceinline__ walk_rsrc_t walk_node_rsrc(const uint2* __restrict__ 
     "v_lshl_add_u32 %[sp], %[t], 11, %[stkb]\n"                                                 \
     "ds_read_b64 v[42:43], %[sp]\n"             /* :134-136 */                                  \
     "v_lshl_add_u32 %[sf], %[t], 23, %[sfc]\n"  /* :133 2^(scale-23) */                         \
-    "v_lshlrev_b32_e64 %[t2], %[t], -1\n"                                                       \
+    "v_lshlrev_b32_e64 %[t2], %[t], -1\n"       /* (the steps in cs, m, t2 are dead by now) */  \
     "v_bfe_u32 %[cx], %[px], %[t], 1\n"         /* :137-143 */                                  \
     "v_bfe_u32 %[cy], %[py], %[t], 1\n"                                                         \
     "v_bfe_u32 %[cz], %[pz], %[t], 1\n"                                                         \
@@ -229,20 +232,20 @@ __device__ __forceinline__ uint32_t ray_walk(Ray& r, bool active, const uint2* _
     const uint32_t sfc = 104u << 23;            // (scale - 23 + 127) << 23 = (scale << 23) + (104 << 23)
     const walk_rsrc_t rsrc = walk_node_rsrc(nodes);
     uint64_t sentry, sleaf, slod, srun, sin_, sx, sy, st;   // sx / sy: the x / y step masks of the advance
-    uint32_t siter, cs, m, t, t2, kind = 0u, ssteps = 0u, sb;
-    float tc, cx, cy, cz, hx, hy, hz;
+    uint32_t siter, m, t, t2, kind, ssteps = 0u, sb;
+    float tc, cx, cy, cz;
     float px = r.px, py = r.py, pz = r.pz, t_min = r.t_min, t_max = r.t_max, sf = r.scale_f;
     uint32_t pid = r.parent_id, ndx = r.nd.x, ndy = r.nd.y;
     uint32_t sp = stkb + ((uint32_t)r.scale << 11);          // the level, as the LDS address of its stack row
     uint32_t co = r.child_offset, normal = r.normal, cmpl = COUNT_LANE ? r.complexity : 0u;
 #define VRC_WALK_OPERANDS(COUNT_OPERANDS)                                                                         \
-        : [kind] "+&v"(kind), COUNT_OPERANDS, [sp] "+&v"(sp), [co] "+&v"(co), [normal] "+&v"(normal),                     \
+        : [kind] "=&v"(kind), COUNT_OPERANDS, [sp] "+&v"(sp), [co] "+&v"(co), [normal] "+&v"(normal),                     \
           [px] "+&v"(px), [py] "+&v"(py), [pz] "+&v"(pz), [tmin] "+&v"(t_min), "+{v42}"(pid), "+{v43}"(t_max),            \
           [sf] "+&v"(sf), "+{v46}"(ndx), "+{v47}"(ndy),                                                                \
           [sentry] "=&s"(sentry), [sleaf] "=&s"(sleaf), [slod] "=&s"(slod), [srun] "=&s"(srun), [sin] "=&s"(sin_),    \
           [sx] "=&s"(sx), [sy] "=&s"(sy), [st] "=&s"(st),                                                             \
-          [siter] "=&s"(siter), [cs] "=&v"(cs), [m] "=&v"(m), [t] "=&v"(t), [t2] "=&v"(t2), [tc] "=&v"(tc),           \
-          [cx] "=&v"(cx), [cy] "=&v"(cy), [cz] "=&v"(cz), [hx] "=&v"(hx), [hy] "=&v"(hy), [hz] "=&v"(hz)              \
+          [siter] "=&s"(siter), [m] "=&v"(m), [t] "=&v"(t), [t2] "=&v"(t2), [tc] "=&v"(tc),                           \
+          [cx] "=&v"(cx), [cy] "=&v"(cy), [cz] "=&v"(cz)                                                              \
         : [tcx] "v"(r.tcx), [tcy] "v"(r.tcy), [tcz] "v"(r.tcz), [tox] "v"(r.tox), [toy] "v"(r.toy), [toz] "v"(r.toz), \
           [mirror] "v"(r.mirror), [stkb] "v"(stkb), [rsrc] "s"(rsrc), [nodes] "s"(nodes), [sfc] "s"(sfc), [coef] "v"(coef), [bias] "v"(bias), \
           [sact] "s"(sact)                                                                                             \
