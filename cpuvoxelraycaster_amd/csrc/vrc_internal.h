@@ -84,14 +84,17 @@ hipError_t launch_grid_cast(const uint8_t* cells, int X, int Y, int Z, uint64_t 
 uint32_t tile_wave_lds_bytes();       // LDS job pool per wave of k_render_tile
 uint32_t tile_max_blocks_per_cu();    // register-limited workgroups per CU of k_render_tile
 uint32_t sync_max_blocks_per_cu();    // ... of k_render_sync
-// The stage-synchronous kernels exist in several builds by waves per SIMD: 6 (80 VGPRs; all of them), 7 (72; one-bounce
-// pinhole) and 8 (64; one-bounce, and the pinhole kernels of the 2-bounce extension: 1.950 -> 1.900 ms).  More waves hide more latency and make the end of a launch more ragged; which wins depends on the
-// launch (tools/ab_variants.sh, C3 / C4 / C2 frames, ms):
-//   pinhole + GI, one launch at a time (automatic chunk)   6: 1.399   7: 1.360   8: 1.400
-//   pinhole, whole-spp units, three frames in flight       6: 1.253             8: 1.233   (C5: 18.69 / 18.19)
-//   lens (DOF) + GI                                        6: 1.540   7: 1.543   8: 1.522   (one at a time: 1.657 / 1.663 / 1.641)
-//   short launch (C2: 1280 x 720, primary + shadow, 1 spp) 6: 0.080   7: 0.086   8: 0.092
-// sync_waves_for picks by that table; a caller's vrc_renderer_set_tuning(blocks_per_cu) overrides it.
+// The stage-synchronous kernels exist in several builds by waves per SIMD: 6 (80 VGPRs; all of them), 7 (72; the one-bounce
+// kernels) and 8 (64; the pinhole kernels).  More waves hide more latency, make the end of a launch more ragged and leave
+// fewer registers (spills); which wins depends on the launch.  Round 3, tools/sweep_waves.sh at camera pitch 0 / -0.5 / -1.2
+// (profiles/r03/sweep_waves.txt, sweep_waves_c4.txt), ms per frame at pitch -0.5:
+//   pinhole + GI (C3), one launch at a time (automatic chunk)   6: 1.209   7: 1.163   8: 1.209      (C5: 16.29 / 15.58 / 15.57)
+//   pinhole + GI (C3), whole-spp units, three frames in flight  6: 1.062   7: 1.044   8: 1.039      (C5: 15.60 / 15.32 / 15.14)
+//   lens (DOF) + GI (C4), three frames in flight                6: 1.307   7: 1.294   8: 1.327
+//   lens (DOF) + GI (C4), one at a time                         6: 1.422   7: 1.446   8: 1.410      (pitch 0: 0.910 / 0.942 / 0.926)
+//   short launch (C2: 1280 x 720, primary + shadow, 1 spp)      6: 0.073   7: 0.075   8: 0.082
+// The choice is the same at all three pitches.  sync_waves_for picks by that table; a caller's
+// vrc_renderer_set_tuning(blocks_per_cu) overrides it.
 uint32_t sync_waves_for(bool pinhole, bool one_bounce, bool use_gi, bool whole_spp_units, uint64_t pixel_samples, uint32_t requested);
 bool camera_is_pinhole(const vrc_camera& cam);   // the host's predicate for the pinhole kernels (see launch_render)
 hipError_t launch_render(const FrameArgs& a, uint32_t grid_blocks, int kernel, hipStream_t st, const char** launched);

@@ -1428,8 +1428,9 @@ VRC_SYNC_KERNEL(k_render_sync_pinhole_w7, true, true, false, 7)
 VRC_SYNC_KERNEL(k_render_sync_pinhole_resolved_w7, true, true, true, 7)
 VRC_SYNC_KERNEL(k_render_sync_pinhole_w8, true, true, false, 8)
 VRC_SYNC_KERNEL(k_render_sync_pinhole_resolved_w8, true, true, true, 8)
-VRC_SYNC_KERNEL(k_render_sync_w8, false, true, false, 8)
-VRC_SYNC_KERNEL(k_render_sync_resolved_w8, false, true, true, 8)
+// ... the lens (DOF) one-bounce kernel at 7: at 64 registers it spills too much to gain from the eighth wave
+VRC_SYNC_KERNEL(k_render_sync_w7, false, true, false, 7)
+VRC_SYNC_KERNEL(k_render_sync_resolved_w7, false, true, true, 7)
 // ... and the pinhole kernels of the 2-bounce extension at 8
 VRC_SYNC_KERNEL(k_render_sync_pinhole2_w8, true, false, false, 8)
 VRC_SYNC_KERNEL(k_render_sync_pinhole2_resolved_w8, true, false, true, 8)
@@ -1611,14 +1612,19 @@ uint32_t tile_max_blocks_per_cu() { return VRC_TILE_MIN_WAVES; }
 uint32_t sync_max_blocks_per_cu() { return VRC_SYNC_MIN_WAVES; }
 uint32_t sync_waves_for(bool pinhole, bool one_bounce, bool use_gi, bool whole_spp_units, uint64_t pixel_samples, uint32_t requested)
 {
+    // the builds that exist: 6 for every kernel; pinhole one-bounce 7 and 8; lens one-bounce 7; pinhole two-bounce 8
     if (!one_bounce && !pinhole) return VRC_SYNC_MIN_WAVES;            // 2-bounce extension with a lens: the one build
-    if (requested)                                                     // the caller's choice, rounded down to a build that exists
-        return requested >= 8u ? 8u : (requested == 7u && pinhole && one_bounce ? 7u : VRC_SYNC_MIN_WAVES);
+    if (requested) {                                                   // the caller's choice, rounded down to a build that exists
+        if (!one_bounce) return requested >= 8u ? 8u : VRC_SYNC_MIN_WAVES;
+        if (!pinhole) return requested >= 7u ? 7u : VRC_SYNC_MIN_WAVES;
+        return requested >= 8u ? 8u : (requested == 7u ? 7u : VRC_SYNC_MIN_WAVES);
+    }
+    // tools/sweep_waves.sh (profiles/r03/sweep_waves.txt: C2..C5 x pitch 0 / -0.5 / -1.2 x frames in flight 3 / 1)
     if (!one_bounce) return whole_spp_units ? 8u : VRC_SYNC_MIN_WAVES;
-    if (pinhole && whole_spp_units) return 8u;                         // also on an eighth of the frame (tools/shard_inflight.py)
-    if (pixel_samples * (use_gi ? 2u : 1u) < (4ull << 20)) return VRC_SYNC_MIN_WAVES;   // short launch
-    if (pinhole) return use_gi ? 7u : VRC_SYNC_MIN_WAVES;
-    return use_gi ? 8u : VRC_SYNC_MIN_WAVES;
+    if (!pinhole) return whole_spp_units ? 7u : VRC_SYNC_MIN_WAVES;   // lens: 7 by 1-2.4 % with frames in flight, 6 alone on the chip
+    if (whole_spp_units) return 8u;                                    // also on an eighth of the frame (tools/shard_inflight.py)
+    if (pixel_samples * (use_gi ? 2u : 1u) < (4ull << 20)) return VRC_SYNC_MIN_WAVES;   // short launch (C2)
+    return use_gi ? 7u : VRC_SYNC_MIN_WAVES;
 }
 
 bool camera_is_pinhole(const vrc_camera& cam)
@@ -1658,7 +1664,7 @@ hipError_t launch_render(const FrameArgs& a, uint32_t grid_blocks, int kernel, h
             (waves == 8u && pinhole && one)  ? (fused ? VRC_BUILD(k_render_sync_pinhole_resolved_w8) : VRC_BUILD(k_render_sync_pinhole_w8)) :
             (waves == 8u && pinhole)         ? (fused ? VRC_BUILD(k_render_sync_pinhole2_resolved_w8) : VRC_BUILD(k_render_sync_pinhole2_w8)) :
             (waves == 7u && pinhole && one)  ? (fused ? VRC_BUILD(k_render_sync_pinhole_resolved_w7) : VRC_BUILD(k_render_sync_pinhole_w7)) :
-            (waves == 8u && one)             ? (fused ? VRC_BUILD(k_render_sync_resolved_w8) : VRC_BUILD(k_render_sync_w8)) :
+            (waves == 7u && one)             ? (fused ? VRC_BUILD(k_render_sync_resolved_w7) : VRC_BUILD(k_render_sync_w7)) :
             pinhole ? (one ? (fused ? VRC_BUILD(k_render_sync_pinhole_resolved) : VRC_BUILD(k_render_sync_pinhole))
                            : (fused ? VRC_BUILD(k_render_sync_pinhole2_resolved) : VRC_BUILD(k_render_sync_pinhole2)))
                     : (one ? (fused ? VRC_BUILD(k_render_sync_resolved) : VRC_BUILD(k_render_sync))

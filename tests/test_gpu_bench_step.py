@@ -94,10 +94,10 @@ def test_bench_step_c3_pinhole(built, heights, textures):
 
 
 def test_bench_step_c4_dof(built, heights, textures):
-    """bench.py --config c4 (aperture 0.5, focal length 60 voxels as bench.py sets it): k_render_sync_resolved_w8"""
+    """bench.py --config c4 (aperture 0.5, focal length 60 voxels as bench.py sets it): k_render_sync_resolved_w7"""
     import cpuvoxelraycaster_amd as vrc
     depth, W, H, spp = 9, 1920, 1080, 4
     svo = vrc.LSVO.fromFastNoiseTerrain(depth, seed=1337, textures=textures)
     nodes = svo.downloadNodes()
     cam = vrc.reference_camera(depth, pitch=-0.5, aperture=0.5, focal_length=60.0 * (1 << depth) / 512.0)
-    check(vrc, svo, nodes, textures, cam, W, H, spp, depth, "k_render_sync_resolved_w8")
+    check(vrc, svo, nodes, textures, cam, W, H, spp, depth, "k_render_sync_resolved_w7")

@@ -56,9 +56,9 @@ def test_forced_builds_equal_the_oracle(scene, textures, aperture):
             assert (st.rays, st.sum_complexity) == (rays, steps), (blocks, fused)
             names.add(rc.lastKernel())
     base = "k_render_sync_pinhole" if aperture == 0.0 else "k_render_sync"
-    want = {base, base + "_resolved", base + "_w8", base + "_resolved_w8"}
+    want = {base, base + "_resolved", base + "_w7", base + "_resolved_w7"}
     if aperture == 0.0:
-        want |= {base + "_w7", base + "_resolved_w7"}
+        want |= {base + "_w8", base + "_resolved_w8"}
     assert names == want
 
 
@@ -74,7 +74,8 @@ def test_library_choice_at_baseline_size(textures):
         (pin, True, True, spp, 1, "k_render_sync_pinhole_w8"),
         (pin, True, False, spp, 1, "k_render_sync_pinhole_w8"),
         (pin, False, False, 1, 1, "k_render_sync_pinhole"),
-        (dof, False, True, spp, 1, "k_render_sync_w8"),
+        (dof, False, True, spp, 1, "k_render_sync"),
+        (dof, True, True, spp, 1, "k_render_sync_w7"),
         (dof, False, False, spp, 1, "k_render_sync"),
         (pin, True, True, spp, 2, "k_render_sync_pinhole2_w8"),
         (pin, False, True, spp, 2, "k_render_sync_pinhole2"),
