@@ -715,13 +715,14 @@ def main():
             issue["floor_note"] = (f"profiles/issue_model.json was made from kernel sources {model.get('source_hash')}, this tree's are "
                                    f"{kernel_source_hash()}: re-run tools/issue_model.py")
             model = None
-        if model is not None and not (args.config in ("c3",) and abs(args.pitch + 0.5) < 1e-9 and args.kernel == 2):
-            issue["floor_note"] = "block issue frequencies exist for the c3 workload at pitch -0.5 only (tests/tools/path_schedule.py --dump)"
-            model = None
-        if model is not None:
+        walks_model = model is not None and args.config == "c3" and abs(args.pitch + 0.5) < 1e-9 and args.kernel == 2
+        if model is not None and not walks_model:
+            issue["floor_note"] = ("block issue frequencies of the walk exist for the c3 workload at pitch -0.5 only (tests/tools/path_schedule.py "
+                                   "--dump): the slow-class resource is left out of this floor")
+        if model is not None and (walks_model or (rec and rec.get("valu_wave_instr"))):
             cyc = model["cycles"]
             tile_samples = my_pixels_per_launch / 64.0 * spp      # 8 x 8 pixel tiles x samples of this rank's launch
-            w = model["walks_per_tile_sample"]
+            w = model["walks_per_tile_sample"] if walks_model else {}
             walk_valu = sum(w.get(c, 0.0) for c in "ABSQP") * tile_samples
             slow = w.get("Q", 0.0) * tile_samples
             pcls = w.get("P", 0.0) * tile_samples
@@ -729,15 +730,15 @@ def main():
             scalar = (float(rec["sq_insts_salu"] + rec.get("sq_insts_branch", 0)) if rec and rec.get("sq_insts_salu")
                       else (w.get("salu", 0.0) + w.get("branch", 0.0)) * tile_samples)
             simds, cus, hz = 1024.0, 256.0, 2.4e9
-            res = {"valu_issue": cyc["valu_arch"] * valu / simds, "slow_class_unit": (cyc["slow"] * slow + cyc["p"] * pcls) / simds,
-                   "scalar_unit": cyc["salu_per_cu"] * scalar / cus}
+            res = {"valu_issue": cyc["valu_arch"] * valu / simds, "scalar_unit": cyc["salu_per_cu"] * scalar / cus}
+            if walks_model:
+                res["slow_class_unit"] = (cyc["slow"] * slow + cyc["p"] * pcls) / simds
             binding = max(res, key=res.get)
             floor_ms = res[binding] / hz * 1e3
             issue.update({
                 "floor_ms": round(floor_ms, 4), "issue_frac": round(floor_ms / kernel_ms, 4), "binding_resource": binding,
                 "floor_ms_by_resource": {k: round(v / hz * 1e3, 4) for k, v in res.items()},
                 "floor_ms_at_measured_ceiling": round(cyc["valu_measured_ceiling"] * valu / simds / hz * 1e3, 4),
-                "valu_wave_instr_walks_model": int(walk_valu), "slow_class_wave_instr_walks_model": int(slow),
                 "valu_wave_instr_used": int(valu), "valu_count_from": "rocprofv3 SQ_INSTS_VALU (profiles/traffic.json)" if rec and rec.get("valu_wave_instr") else "model (walks only: a lower bound)",
                 "floor_is": f"max over resources of the cycles below which the launch's instruction streams cannot issue: {cyc['valu_arch']} cycles per VALU "
                             f"wave-instruction per SIMD (a wave64 instruction is two passes of the SIMD-32, MI355X_MICROARCH.md), {cyc['slow']} per "
@@ -745,6 +746,8 @@ def main():
                             "instruction of a CU's one scalar unit; 1024 SIMDs, 256 CUs, 2.4 GHz.  floor_ms_at_measured_ceiling prices VALU issue at "
                             f"{cyc['valu_measured_ceiling']} cycles, the fastest any plain-VALU stream issued in the microbenchmarks (profiles/r03/op_pairs.txt) -- "
                             "the kernel's own streams issue at about that rate, i.e. only fewer instructions (or fuller lanes, see lane_utilisation) make the frame faster"})
+            if walks_model:
+                issue.update({"valu_wave_instr_walks_model": int(walk_valu), "slow_class_wave_instr_walks_model": int(slow)})
             roof["bound"] = "valu_issue"
             roof["bound_note"] = ("instruction issue (roofline.issue) is what binds; achieved / peak / frac keep the nominal HBM form SURVEY 8d "
                                   "asks for (algorithmic bytes / kernel time), traffic is the measured HBM traffic")
