@@ -75,3 +75,76 @@ def test_dist_path_logs_verified_the_gathered_frame():
         d = load(name)
         assert d["config"]["gathered_frame_equals_unsharded"] is True, name
         assert d["config"]["ranks_in_process_group"] == d["n_gpus"] or name.startswith("force_dist")
+
+
+# ---- round 3: the same contract on this round's kept lines, plus what the round added (spread over timed blocks, issue floor)
+R3 = os.path.join(ROOT, "profiles", "r03")
+
+
+def load3(name):
+    with open(os.path.join(R3, name)) as f:
+        return json.loads(f.read().strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize("name", ["final_bench.json.log", "final_bench_steps20.json.log", "final_bench_inflight1.json.log",
+                                  "final_bench_c2.json.log", "final_bench_c4.json.log", "final_bench_c5.json.log"])
+def test_round3_bench_line_contract(name):
+    d = load3(name)
+    for k, t in DRIVER_KEYS.items():
+        assert isinstance(d[k], t), k
+    assert d["vs_baseline"] is None and d["higher_is_better"] is True and d["unit"] == "Mrays/s" and d["n_gpus"] == 1
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    # the nominal HBM form stays ...
+    assert r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) < 0.01 * r["achieved"]
+    assert r["kernel_ms"] <= d["ms_per_step"] * 1.001 and r["achieved"] < r["peak"]
+    assert r["traffic"] is not None and r["traffic"] < r["algorithmic_bytes_per_launch"]
+    assert os.path.exists(os.path.join(ROOT, r["traffic_detail"]["profile"]))
+    # ... and the bound that binds is named, with its floor: no faster than the floor, and the floor is the largest resource
+    assert r["bound"] == "valu_issue"
+    i = r["issue"]
+    assert 0.3 < i["issue_frac"] <= 1.0 and abs(i["issue_frac"] - i["floor_ms"] / r["kernel_ms"]) < 2e-3
+    assert i["floor_ms"] == max(i["floor_ms_by_resource"].values()) and i["binding_resource"] in i["floor_ms_by_resource"]
+    assert abs(i["floor_ms"] - 2.0 * i["valu_wave_instr_used"] / 1024 / 2.4e9 * 1e3) < 2e-3 or i["binding_resource"] != "valu_issue"
+    # the median block is the one reported
+    b = d["extra"]["ms_per_step_blocks"]
+    lo, med, hi = b["min_median_max"]
+    assert b["blocks"] >= 5 and b["steps_per_block"] == d["steps"] and lo <= med <= hi and abs(med - d["ms_per_step"]) < 1e-3
+    assert abs(d["value"] - d["config"]["rays_per_frame"] / (d["ms_per_step"] * 1e-3) / 1e6) < 0.01 * d["value"]
+
+
+def test_round3_headline_line():
+    d = load3("final_bench.json.log")
+    assert d["steps"] == 100 and d["config"]["frames_in_flight"] == 3 and d["roofline"]["kernel"] == "k_render_sync_pinhole_resolved_w8"
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "Mrays/s" and c["cores"] >= 1
+    one = d["extra"]["one_frame_in_flight"]
+    assert one["kernel_ms"] <= one["ms_per_step"] and one["blocks"] >= 3
+    lo, med, hi = one["ms_per_step_blocks"]
+    assert lo <= med <= hi and med == one["ms_per_step"]
+    # rocprofv3 --stats of the same commands (tools/pmc_roofline.sh): alone on the chip rocprof's average = the event time
+    import csv
+
+    def avg_ms(csv_name):
+        with open(os.path.join(R3, csv_name)) as f:
+            for row in csv.DictReader(f):
+                if row["Name"].startswith("k_render"):
+                    return row["Name"], float(row["AverageNs"]) / 1e6
+        raise AssertionError(csv_name)
+    name1, ms1 = avg_ms("final_c3_inflight1_kernel_stats.csv")
+    assert name1 == one["kernel"] and abs(ms1 - one["kernel_ms"]) < 0.02 * ms1
+    name3, ms3 = avg_ms("final_c3_kernel_stats.csv")
+    assert name3 == d["roofline"]["kernel"] and abs(ms3 - d["roofline"]["kernel_ms_bracketed"]) < 0.05 * ms3
+
+
+def test_round3_dist_path_logs_verified_the_gathered_frame():
+    for name in ("force_dist_bench.json.log", "force_dist_root_bench.json.log", "force_dist_peer_bench.json.log",
+                 "gloo2_bench.json.log", "gloo2_peer_bench.json.log"):
+        d = load3(name)
+        assert d["config"]["gathered_frame_equals_unsharded"] is True, name
+    assert "direct peer writes" in load3("gloo2_peer_bench.json.log")["config"]["sharding"]
+    for name in ("peer_write_world2.json.log", "peer_write_world3.json.log"):
+        assert load3(name)["composed_frame_equals_unsharded"] == [True] * 9
+    for name in ("cpp_rccl_all_world1.json.log", "cpp_rccl_root_world1.json.log"):
+        assert load3(name)["gathered_frames_equal_unsharded"] is True
