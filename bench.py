@@ -551,6 +551,34 @@ def main():
             other = {"exchange": state["gather"], "error": repr(e)[:300]}
         state["gather"] = args.gather
 
+    # N > 1: the chip time per launch above spans this rank's exchange / unpack kernels and waits as well: time the
+    # frame kernel of this rank's shard on its own, untimed extra, same renderers / streams / unit policy, no exchange
+    render_only_ms = None
+    if dist_on:
+        dist.barrier()                                         # rank 0 has compared the gathered frame (peer writes land in ITS framebuffers)
+        n_ro = max(2 * F, min(args.steps, 30))
+        evs = []
+        for k in range(F + n_ro):
+            rc, ts = rcs[k % F], tstreams[k % F]
+            with torch.cuda.stream(ts):
+                rc.frame_index = k * spp
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(ts)
+                if fused:
+                    rc.renderFrameResolved(cam, spp=spp, dst_ptr=(None if peers is not None else mine[k % n_slots].data_ptr()), stream=ts.cuda_stream,
+                                           row_block=ROW_BLOCK, shard_index=rank, shard_count=world)
+                else:
+                    rc.renderFrame(cam, spp=spp, stream=ts.cuda_stream, row_block=ROW_BLOCK, shard_index=rank, shard_count=world)
+                    rc.resolveShard(ROW_BLOCK, rank, world, None if peers is not None else mine[k % n_slots].data_ptr(), reset=True, stream=ts.cuda_stream)
+                e1.record(ts)
+                if k >= F:
+                    evs.append((e0, e1))
+        torch.cuda.synchronize()
+        render_only_ms = (max(evs[0][0].elapsed_time(b) for _, b in evs[-F:]) / len(evs)) if F > 1 else sum(a.elapsed_time(b) for a, b in evs) / len(evs)
+        for r in rcs:
+            r.stats(reset=True, stream=tstreams[0].cuda_stream)
+        if peers is not None:                                  # those frames went to rank 0's framebuffers without flags:
+            dist.barrier()                                     # nobody reads them, but keep the ranks together
     # untimed extra, N = 1 only: BASELINE config 3's text says "GI 2 bounces"; the reference has ONE indirect bounce
     # (RayContext::gi_bounce is never read), which is what `value` measures -- the 2-bounce EXTENSION
     # (recursive getGlobalIllumination at the GI hit, defined by the oracle) is reported beside it
@@ -686,6 +714,7 @@ def main():
                                  "(= the average duration rocprofv3 --stats reports for this command)"),
                 "kernel_ms_bracketed": round(kernel_ms_bracketed, 4),
                 "kernel_ms_max_rank": round(kernel_ms_max, 4), "algorithmic_bytes_per_launch": int(alg_bytes),
+                "kernel_ms_render_only": (round(render_only_ms, 4) if render_only_ms is not None else None),
                 "achieved_is": "ALGORITHMIC bytes (SURVEY 8d: 8 B per walk-loop iteration + 32 B per pixel) / kernel time -- nominal by "
                                "construction: the tree is L1/L2-resident, see traffic_frac_of_peak, and the binding limit is VALU "
                                "instruction issue, see issue"}
