@@ -757,6 +757,10 @@ extern "C" int vrc_ipc_flags_open(const char* name, uint32_t count, int device, 
     if (rc) return rc;
     const size_t page = 4096, bytes = (((size_t)count * 4u) + page - 1) / page * page;
     int fd = create ? shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600) : shm_open(name, O_RDWR, 0600);
+    if (fd < 0 && create && errno == EEXIST) {                  // a segment of that name left by a run that died: the creator owns the name
+        shm_unlink(name);
+        fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+    }
     if (fd < 0) return fail(VRC_ERR_INVALID, "vrc_ipc_flags_open: shm_open(%s): %s", name, strerror(errno));
     if (create && ftruncate(fd, (off_t)bytes) != 0) {           // a new segment reads as zeros
         const int e = errno; close(fd); shm_unlink(name);

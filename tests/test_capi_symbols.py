@@ -57,6 +57,11 @@ def test_no_gpu_fails_loudly(built):
     nodes = np.zeros(9, vrc.LNODE_DTYPE)
     with pytest.raises(vrc.VrcError):
         vrc.LSVO(nodes, 2)
+    # ... the frame flags of the peer-write exchange as well: no device, no segment left behind
+    f = C.c_void_p()
+    L = vrc.capi.load()
+    assert L.vrc_ipc_flags_open(b"/vrc_test_no_gpu", 8, 0, 1, C.byref(f)) == -2
+    assert not os.path.exists("/dev/shm/vrc_test_no_gpu")
 
 
 def test_replay_reader_matches_reference_format(built, tmp_path):
@@ -98,6 +103,15 @@ def test_argument_validation_needs_no_gpu(built):
     assert L.vrc_resolve_shard(None, 8, 0, 1, None, 0, None) == -1
     assert L.vrc_unpack_shards(None, 16, 16, 8, 2, None, None) == -1
     assert L.vrc_shard_bytes(1920, 1080, 8, 8) == 17 * 8 * 1920 * 4
+    # direct peer writes / frame flags: bad names and counts, null handles
+    f = C.c_void_p()
+    assert L.vrc_ipc_flags_open(b"no_slash", 8, 0, 1, C.byref(f)) == -1
+    assert L.vrc_ipc_flags_open(b"/vrc_x", 0, 0, 1, C.byref(f)) == -1
+    assert L.vrc_ipc_flags_open(None, 8, 0, 1, C.byref(f)) == -1
+    assert L.vrc_stream_write_flag(None, 0, 1, None) == -1 and L.vrc_stream_wait_flag(None, 0, 1, None) == -1
+    assert L.vrc_ipc_flag_value(None, 0) == 0 and L.vrc_ipc_flags_close(None) == 0
+    assert L.vrc_ipc_export_image(None, None) == -1 and L.vrc_ipc_open_image(0, None, None) == -1
+    assert L.vrc_renderer_set_image_target(None, None) == -1
 
 
 def test_bmp_texture_readers(built, tmp_path):
