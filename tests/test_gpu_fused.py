@@ -135,3 +135,47 @@ def test_fused_full_size_c3(built, heights, textures):
     assert not b.readAccum().any()
     sa, sb = a.stats(), b.stats()
     assert (sa.rays, sa.sum_complexity) == (sb.rays, sb.sum_complexity)
+
+
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("chunk", [0, 2, 4])
+def test_image_target_composes_shards_in_place(scene, fused, chunk):
+    """vrc_renderer_set_image_target (the direct-peer-write exchange, here inside one process): N renderers each render their
+    row blocks of the frame and resolve them straight into renderer 0's framebuffer -- full-frame layout, no pack / unpack --,
+    fused into the frame kernel or through vrc_resolve_shard; the composed framebuffer equals the unsharded frame, frame after
+    frame, and the writers' own images stay untouched."""
+    import torch
+    import cpuvoxelraycaster_amd as vrc
+    nodes, svo = scene
+    W, H, spp, RB, N = 203, 117, 4, 8, 3
+    L = vrc.capi.load()
+    cam = vrc.reference_camera(7, pitch=-0.5)
+    parts = [make(vrc, svo, W, H, chunk) for _ in range(N)]
+    ref = make(vrc, svo, W, H, chunk)
+    target = L.vrc_image_device_ptr(parts[0]._h)
+    for p in parts[1:]:
+        p.setImageTarget(target)
+    untouched = [p.readImage() for p in parts[1:]]
+    for frame in range(3):
+        for k, p in enumerate(parts):
+            p.frame_index = frame * spp
+            if fused:
+                p.renderFrameResolved(cam, spp=spp, row_block=RB, shard_index=k, shard_count=N)
+            else:
+                p.renderFrame(cam, spp=spp, row_block=RB, shard_index=k, shard_count=N)
+                p.resolveShard(RB, k, N, None, reset=True)
+        ref.frame_index = frame * spp
+        ref.renderFrameResolved(cam, spp=spp)
+        torch.cuda.synchronize()
+        assert np.array_equal(parts[0].readImage(), ref.readImage()), (fused, chunk, frame)
+        for p, img in zip(parts[1:], untouched):
+            assert np.array_equal(p.readImage(), img)
+    for p in parts[1:]:
+        p.setImageTarget(None)
+    parts[1].frame_index = 0
+    parts[1].renderFrameResolved(cam, spp=spp, row_block=RB, shard_index=1, shard_count=N)
+    own = parts[1].readImage()
+    rows = [y for y in range(H) if (y // RB) % N == 1]
+    ref.frame_index = 0
+    ref.renderFrameResolved(cam, spp=spp)
+    assert np.array_equal(own[rows], ref.readImage()[rows])       # back to its own image
