@@ -148,3 +148,5 @@ def test_round3_dist_path_logs_verified_the_gathered_frame():
         assert load3(name)["composed_frame_equals_unsharded"] == [True] * 9
     for name in ("cpp_rccl_all_world1.json.log", "cpp_rccl_root_world1.json.log"):
         assert load3(name)["gathered_frames_equal_unsharded"] is True
+    for name in ("cpp_peer_write_world2.json.log", "cpp_peer_write_world3.json.log"):
+        assert load3(name)["composed_frames_equal_unsharded"] is True

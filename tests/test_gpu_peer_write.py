@@ -52,3 +52,31 @@ def test_peer_written_frames_equal_unsharded(built, world):
     os.makedirs(log, exist_ok=True)
     with open(os.path.join(log, f"peer_write_world{world}.json.log"), "w") as f:
         f.write(line + "\n")
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_cpp_host_peer_writes(built, tmp_path, world):
+    """the same exchange from a C++ host: tests/cpp/peer_write_main.cpp (vrc_host::HipFramePipeline + HipRayCaster::exportImage /
+    setImageTarget + the frame flags), `world` forked processes on GPU 0"""
+    exe = str(tmp_path / "peer_write_main")
+    libdir = os.path.join(ROOT, "cpuvoxelraycaster_amd")
+    subprocess.check_call(["g++", "-std=c++14", "-O1", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                           os.path.join(ROOT, "tests", "cpp", "peer_write_main.cpp"), "-o", exe,
+                           "-L" + libdir, "-l:libvrc_hip.so", "-L/opt/rocm/lib", "-lamdhip64", "-lpthread",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    data = os.path.join(libdir, "data")
+    p = subprocess.Popen([exe, str(world), "8", "1280", "720", "4", "9", os.path.join(data, "grass_top_16x16.rgb"),
+                          os.path.join(data, "grass_side_16x16.rgb")], env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"),
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        out, err = p.communicate(timeout=60)
+    except subprocess.TimeoutExpired:
+        os.killpg(p.pid, 9)                                    # the forked ranks are in the program's own process group
+        raise AssertionError("peer_write_main timed out")
+    assert p.returncode == 0, out + err
+    d = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
+    assert d["composed_frames_equal_unsharded"] is True and d["world"] == world and d["frames"] == 9 and d["frames_in_flight"] == 3
+    log = os.path.join(ROOT, "gpurun_out", "r03")
+    os.makedirs(log, exist_ok=True)
+    with open(os.path.join(log, f"cpp_peer_write_world{world}.json.log"), "w") as f:
+        f.write(json.dumps(d) + "\n")
