@@ -65,3 +65,29 @@ def test_traffic_records_are_stamped_and_used_only_for_their_sources(monkeypatch
     assert got is None and why
     got, why = bench.pmc_record("no_such_workload")
     assert got is None and why
+
+
+def test_issue_model_reads_the_walk_loop_and_is_current():
+    """tools/issue_model.py parses the asm text of csrc/vrc_walk.h into per-block instruction classes; profiles/issue_model.json
+    (what bench.py prices roofline.issue.floor_ms with) must be the model of THIS tree's loop -- it is regenerated on the CPU
+    (python tools/issue_model.py), so a kernel change that forgets it fails here rather than silently dropping the floor."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    sys.path.insert(0, ROOT)
+    import bench
+    import issue_model
+    nolod, lod = issue_model.block_counts(0, False), issue_model.block_counts(1, False)
+    valu = lambda b: sum(b.get(c, 0) for c in "ABSQP")
+    assert [valu(nolod[k]) for k in ("header", "descend", "advance", "pop")] == [14, 25, 16, 21]
+    assert valu(lod["header"]) == 16 and lod["header"]["Q"] == 6          # + the LOD product and its compare
+    assert all(b.get("P", 0) == 0 for b in nolod.values())               # no packed / lane-access instruction in the loop
+    assert nolod["descend"]["lds"] == 1 and nolod["pop"]["lds"] == 1 and nolod["descend"]["vmem"] == 1 and nolod["pop"]["vmem"] == 1
+    lane = issue_model.block_counts(0, True)                             # per-lane complexity: one VALU more, two scalar fewer
+    assert valu(lane["header"]) == 15 and lane["header"]["salu"] == nolod["header"]["salu"] - 2
+    doc = json.load(open(os.path.join(ROOT, "profiles", "issue_model.json")))
+    assert doc["blocks_no_lod"] == nolod and doc["blocks_lod"] == lod
+    assert doc["source_hash"] == bench.kernel_source_hash()
+    freq = json.load(open(os.path.join(ROOT, doc["frequencies"])))
+    pts = issue_model.per_tile_sample(freq, nolod, lod)
+    assert abs(sum(pts.get(c, 0) for c in "ABSQP") - sum(doc["walks_per_tile_sample"].get(c, 0) for c in "ABSQP")) < 0.1
+    f = issue_model.floor_cycles(1000.0, 100.0, 0.0, 400.0)
+    assert f["valu_arch"] == 2000.0 and f["slow_unit"] == 430.0 and abs(f["scalar_unit"] - 440.0) < 1e-9
