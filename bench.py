@@ -238,10 +238,11 @@ def main():
     ap.add_argument("--inflight", type=int, default=0,
                     help="frames in flight per GPU (renderers / streams used round-robin); 1 = one stream, each frame starts "
                          "when the previous one has ended; 0 = default: 3")
-    ap.add_argument("--gather", default="all", choices=["all", "root", "peer"],
-                    help="N > 1: how the RGBA8 row-block shards meet: 'all' = RCCL all-gather (every rank ends up with the "
-                         "frame), 'root' = RCCL gather to rank 0, the presenting rank (north_star / SURVEY 8e: 1/N of the "
-                         "bytes on the wire), 'peer' = no collective: every rank's frame kernel writes its rows straight into "
+    ap.add_argument("--gather", default="root", choices=["all", "root", "peer"],
+                    help="N > 1: how the RGBA8 row-block shards meet: 'root' (default) = RCCL gather to rank 0, the presenting rank "
+                         "(north_star / SURVEY 8e 'RCCL gather of the RGBA8 framebuffer': every other rank sends its shard over one "
+                         "direct xGMI hop, 1/N of the all-gather's bytes on the wire), 'all' = RCCL all-gather (every rank ends up "
+                         "with the frame; measured right after the timed region as extra.other_exchange_form), 'peer' = no collective: every rank's frame kernel writes its rows straight into "
                          "rank 0's framebuffer (hipIpc mapping over xGMI, interprocess events; SURVEY 8e 'direct peer writes')")
     ap.add_argument("--fused", default="auto", choices=["auto", "0", "1"],
                     help="resolve + pack + reset inside the frame kernel (vrc_render_frame_resolved) instead of a second kernel; "
