@@ -606,16 +606,16 @@ int render_impl(vrc_renderer* r, const vrc_camera* cam, const vrc_frame_params* 
     a.tile_done = r->d_tile_done;
     a.resolve_dst = (uint32_t*)dst;
     uint64_t want = (items + VRC_RENDER_BLOCK - 1) / VRC_RENDER_BLOCK;
-    // k_render_tile: (depth-1)*2 KiB of stacks + 21 KiB of job pools + 1.5 KiB of tables per workgroup
+    // k_render_tile: depth * 1 KiB of stacks + 21 KiB of job pools + 1.5 KiB of tables per workgroup
     // (38.5 KiB at depth 9): at most 4 fit a CU's 160 KiB; 120 VGPRs allow 4 waves per SIMD as well
     uint32_t bpc = tuning.blocks_per_cu;
     if (tuning.kernel == VRC_KERNEL_TILE) {
-        const uint32_t lds = (s->depth - 1) * 2048u + 4u * vrc::tile_wave_lds_bytes() + 1536u;
+        const uint32_t lds = s->depth * 1024u + 4u * vrc::tile_wave_lds_bytes() + 1536u;
         const uint32_t fit = 163840u / lds;
         if (bpc > fit) bpc = fit;
         if (bpc > vrc::tile_max_blocks_per_cu()) bpc = vrc::tile_max_blocks_per_cu();
     } else if (tuning.kernel == VRC_KERNEL_SYNC) {
-        const uint32_t lds = (s->depth - 1) * 2048u + 1536u + 128u;
+        const uint32_t lds = s->depth * 1024u + 1536u + 128u;
         const uint32_t fit = 163840u / lds;
         // which build of the kernel (waves per SIMD = workgroups per CU): by the kind of launch, or the caller's choice
         const bool whole_spp = a.p.use_samples && a.p.spp > 1 && tuning.sample_chunk >= a.p.spp;

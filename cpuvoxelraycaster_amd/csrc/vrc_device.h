@@ -112,6 +112,7 @@ __device__ __forceinline__ float get_rand(uint32_t k, float mn, float mx)
 }
 
 constexpr int SVO_MAX = 23;  // lsvo.hpp:37
+typedef uint32_t stack_t;    // one stack entry: a parent index (see ray_step); a walk needs `depth` rows of them
 // Safety net (same constant as the oracle): no finite ray needs anywhere near
 // this many loop iterations; guarantees the kernels terminate.
 constexpr uint32_t MAX_ITERATIONS = 65536u;
@@ -121,7 +122,7 @@ struct Ray {
     float tcx, tcy, tcz;      // t_coef   :47
     float tox, toy, toz;      // t_offset :48-52
     float px, py, pz;         // pos      :63
-    float t_min, t_max, h;    // :54-58
+    float t_min, t_max, h;    // :54-58; t_max stays min(1, exit of the root) during the walk (see ray_step)
     float scale_f;            // :64
     uint32_t parent_id;       // :60
     int scale;                // :62 (int8_t in the reference; values stay in [0,23])
@@ -189,13 +190,21 @@ __device__ __forceinline__ bool ray_setup(Ray& r, const uint2 root,
 
 // One iteration of the while loop at lsvo.hpp:72-146.  `stk` points at this
 // lane's column of the LDS stack, STRIDE = lanes per row, so slot s lives at
-// stk[s*stride]; slots are (scale - DEPTH_OFFSET - 1) in [0, depth-2].
+// stk[s*stride]; slots are (scale - DEPTH_OFFSET) in [0, depth-1]: one per scale a parent can have (slot 0, the scale of the
+// leaf voxels, is only written at the end of a walk: the parent of the hit, see ray_walk).
+// The stack holds parent indices only.  The reference also keeps t_max per level (:97-100, :134-136), but t_max is always
+// min(1, exit of the parent's cell): :57-58 set it so for the root, :110 keeps it -- tc_max, the exit of the child cell, is
+// never larger than the exit of the cell around it (x -> x * t_coef - t_offset is monotone in float arithmetic as well, and
+// a child's corner is never below its parent's) --, :134-136 restore it.  So tv_max (:86) = min(1, tc_max) = min(T1, tc_max)
+// and `t_min <= t_max` (:81) = `t_min <= T1` with the per-ray constant T1 = min(1, exit of the root) that ray_setup leaves
+// in r.t_max: t_min, the exit of a cell inside the parent, never exceeds the parent's exit once the ray is inside the cube.
+// (oracle/vrc_walk_model.c restates this formulation on the CPU; tests/test_walk_model.py holds it to the oracle.)
 // Returns the loop condition for the next iteration.
 // LOD = false: the caller guarantees ray_size_coef == 0 and ray_size_bias == 0 (primary and
 // shadow rays, raycaster.hpp:131,153).  Then tc_max * 0 + 0 is 0 (or NaN for an infinite
 // tc_max) and never >= scale_f > 0, so the LOD test of :82 cannot fire and is not evaluated.
 template <int STRIDE, bool LOD = true>
-__device__ __forceinline__ bool ray_step(Ray& r, const uint2* __restrict__ nodes, uint2* stk,
+__device__ __forceinline__ bool ray_step(Ray& r, const uint2* __restrict__ nodes, stack_t* stk,
                                          int depth, float coef, float bias)
 {
     const int depth_off = SVO_MAX - depth;
@@ -228,7 +237,7 @@ __device__ __forceinline__ bool ray_step(Ray& r, const uint2* __restrict__ nodes
         const float thy = half * r.tcy + cy;
         const float thz = half * r.tcz + cz;
         if (tc_max < r.h)                                               // :97-100
-            stk[(r.scale - depth_off - 1) * STRIDE] = make_uint2(r.parent_id, f2u(r.t_max));
+            stk[(r.scale - depth_off) * STRIDE] = r.parent_id;
         r.h = tc_max;                                                   // :101
         r.parent_id += nd.y + child_shift;                              // :103
         r.nd = nodes[r.parent_id];
@@ -239,7 +248,7 @@ __device__ __forceinline__ bool ray_step(Ray& r, const uint2* __restrict__ nodes
         r.px += bx ? half : 0.0f;      // x + 0 == x bit for bit (x is never -0 here)
         r.py += by ? half : 0.0f;
         r.pz += bz ? half : 0.0f;
-        r.t_max = tv_max;                                               // :110
+        // :110 t_max = tv_max: not kept (see above)
         // :72 `scale < 23 && scale > N` holds after every descend for N <= VRC_MAX_DEPTH = 11: leaf
         // level children sit at scale 23 - N, so a descend ends at scale >= 24 - N >= 13 > N.
         return true;
@@ -272,10 +281,8 @@ __device__ __forceinline__ bool ray_step(Ray& r, const uint2* __restrict__ nodes
             return false;
         }
         r.scale_f = u2f((uint32_t)(r.scale - SVO_MAX + 127) << SVO_MAX);  // :133
-        const uint2 entry = stk[(r.scale - depth_off - 1) * STRIDE];     // :134-136
-        r.parent_id = entry.x;
+        r.parent_id = stk[(r.scale - depth_off) * STRIDE];               // :134-136
         r.nd = nodes[r.parent_id];
-        r.t_max = u2f(entry.y);
         // :137-143  (i >> scale) << scale == i & (~0 << scale); child bit = bit `scale` of i
         const uint32_t keep = 0xffffffffu << r.scale;
         r.px = u2f(ipx & keep); r.py = u2f(ipy & keep); r.pz = u2f(ipz & keep);
@@ -292,7 +299,7 @@ namespace vrc {
 
 // The whole walk of one ray.  LOD_MODE: 0 = coef == bias == 0 (primary / shadow rays), 1 = bias == 0, 2 = general.
 template <int STRIDE, int LOD_MODE>
-__device__ __forceinline__ void ray_run(Ray& r, bool active, const uint2* __restrict__ nodes, uint2* stk,
+__device__ __forceinline__ void ray_run(Ray& r, bool active, const uint2* __restrict__ nodes, stack_t* stk,
                                         int depth, float coef, float bias)
 {
 #ifdef VRC_WALK_CPP
@@ -326,7 +333,7 @@ __device__ __forceinline__ void book_walk_lanes(unsigned long long* ctr, uint32_
 }
 
 template <int STRIDE, int LOD_MODE>
-__device__ __forceinline__ void ray_run_total(Ray& r, bool active, const uint2* __restrict__ nodes, uint2* stk,
+__device__ __forceinline__ void ray_run_total(Ray& r, bool active, const uint2* __restrict__ nodes, stack_t* stk,
                                               int depth, float coef, float bias, unsigned long long* ctr)
 {
 #if defined(VRC_WALK_CPP) || defined(VRC_PROBE)

@@ -37,7 +37,7 @@ __device__ __forceinline__ void cast_rays_body(const uint2* __restrict__ nodes, 
                                                const float* __restrict__ coef_a, const float* __restrict__ bias_a,
                                                vrc_hit* __restrict__ out)
 {
-    extern __shared__ uint2 lds_stack[];  // [depth-1][blockDim.x]
+    extern __shared__ stack_t lds_stack[];  // [depth][blockDim.x]
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float ox = org[3 * i + 0], oy = org[3 * i + 1], oz = org[3 * i + 2];
@@ -47,7 +47,7 @@ __device__ __forceinline__ void cast_rays_body(const uint2* __restrict__ nodes, 
     const uint2 root = nodes[0];
     Ray r;
     bool active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
-    uint2* stk = lds_stack + threadIdx.x;
+    stack_t* stk = lds_stack + threadIdx.x;
     ray_run<256, LOD ? 2 : 0>(r, active, nodes, stk, depth, coef, bias);
     Hit h;
     ray_finish(r, depth, ox, oy, oz, dx, dy, dz, h);
@@ -180,9 +180,9 @@ __device__ __forceinline__ bool pixel_selected(const vrc_frame_params& p, uint32
 extern "C" __global__ void __launch_bounds__(VRC_RENDER_BLOCK)
 k_render(const FrameArgs a)
 {
-    extern __shared__ uint2 lds_dyn[];                 // [depth-1][VRC_RENDER_BLOCK] stack, then 1536 B textures
-    uint2* stk = lds_dyn + threadIdx.x;
-    uint8_t* tex = reinterpret_cast<uint8_t*>(lds_dyn + (a.depth - 1) * VRC_RENDER_BLOCK);
+    extern __shared__ stack_t lds_dyn[];               // [depth][VRC_RENDER_BLOCK] stack, then 1536 B textures
+    stack_t* stk = lds_dyn + threadIdx.x;
+    uint8_t* tex = reinterpret_cast<uint8_t*>(lds_dyn + a.depth * VRC_RENDER_BLOCK);
     for (uint32_t i = threadIdx.x; i < 1536u / 4u; i += VRC_RENDER_BLOCK)
         reinterpret_cast<uint32_t*>(tex)[i] = reinterpret_cast<const uint32_t*>(a.tex)[i];
     __syncthreads();
@@ -506,9 +506,9 @@ constexpr uint32_t TILE_WAVE_LDS = TILE_POOL * 4u * 5u + TILE_POOL;   // px,py,p
 extern "C" __global__ void __launch_bounds__(VRC_RENDER_BLOCK, VRC_TILE_MIN_WAVES)
 k_render_tile(const FrameArgs a)
 {
-    extern __shared__ uint2 lds_dyn[];   // [depth-1][256] stack | 4 x per-wave pool | 1536 B textures
-    uint2* stk = lds_dyn + threadIdx.x;
-    uint8_t* lds_tail = reinterpret_cast<uint8_t*>(lds_dyn + (a.depth - 1) * VRC_RENDER_BLOCK);
+    extern __shared__ stack_t lds_dyn[];   // [depth][256] stack | 4 x per-wave pool | 1536 B textures
+    stack_t* stk = lds_dyn + threadIdx.x;
+    uint8_t* lds_tail = reinterpret_cast<uint8_t*>(lds_dyn + a.depth * VRC_RENDER_BLOCK);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     float* pool_px = reinterpret_cast<float*>(lds_tail + wave * TILE_WAVE_LDS);
     float* pool_py = pool_px + TILE_POOL;
@@ -845,7 +845,7 @@ __device__ __forceinline__ uint32_t probe_wave_max(uint32_t v)
 // ray from the point (bp, bn), cast with LOD coefficient 0.5; if it hits, a shadow ray from the GI hit towards the
 // light.  Called by all lanes of a wave whose pixel-sample has a primary hit (`in exec`); the two walks are wave-wide.
 template <bool ONE_BOUNCE>   // true: gi_bounces == 1 is known (the reference's semantics), the chain is straight-line code
-__device__ __forceinline__ float gi_chain(const uint2* __restrict__ nodes, uint2* stk, const uint2 root, const int depth,
+__device__ __forceinline__ float gi_chain(const uint2* __restrict__ nodes, stack_t* stk, const uint2 root, const int depth,
                                           const float n_normalizer, const float lx, const float ly, const float lz,
                                           const uint32_t gi_bounces_rt, const uint32_t seed, const uint32_t fr, const uint32_t pix,
                                           float base_px, float base_py, float base_pz, float base_nx, float base_ny, float base_nz,
@@ -909,7 +909,7 @@ __device__ __forceinline__ float gi_chain(const uint2* __restrict__ nodes, uint2
 // rejects gi_bounces > 2, launch_render sends gi_bounces <= 1 to the one-bounce kernels).  Same operations in the same
 // order as gi_chain<false> with gi_bounces = 2 -- level 0 from the primary hit with draws 2, 3, level 1 from the GI hit with
 // draws 4, 5, gi = max(0, acc0 + dot_gi0 * max(0, acc1)) -- without the loop-carried level / draw / base state.
-__device__ __forceinline__ float gi_two_levels(const uint2* __restrict__ nodes, uint2* stk, const uint2 root, const int depth,
+__device__ __forceinline__ float gi_two_levels(const uint2* __restrict__ nodes, stack_t* stk, const uint2 root, const int depth,
                                                const float n_normalizer, const float lx, const float ly, const float lz,
                                                const uint32_t seed, const uint32_t fr, const uint32_t pix,
                                                const float b0px, const float b0py, const float b0pz,
@@ -1020,9 +1020,9 @@ __device__ __forceinline__ uint32_t albedo_of(const uint8_t* tex, const Hit& h)
 template <bool PINHOLE, bool ONE_BOUNCE, bool FUSED>
 __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
 {
-    extern __shared__ uint2 lds_dyn[];   // [depth-1][256] stack | 1536 B textures | 4 waves x 4 counters
-    uint2* stk = lds_dyn + threadIdx.x;
-    uint8_t* tex = reinterpret_cast<uint8_t*>(lds_dyn + (a.depth - 1) * VRC_RENDER_BLOCK);
+    extern __shared__ stack_t lds_dyn[];   // [depth][256] stack | 1536 B textures | 4 waves x 4 counters
+    stack_t* stk = lds_dyn + threadIdx.x;
+    uint8_t* tex = reinterpret_cast<uint8_t*>(lds_dyn + a.depth * VRC_RENDER_BLOCK);
     const uint32_t lane = threadIdx.x & 63u;
     for (uint32_t i = threadIdx.x; i < 1536u / 4u; i += VRC_RENDER_BLOCK)
         reinterpret_cast<uint32_t*>(tex)[i] = reinterpret_cast<const uint32_t*>(a.tex)[i];
@@ -1588,7 +1588,7 @@ hipError_t launch_cast_rays(const void* nodes, int depth, uint64_t n, const floa
     if (n == 0) return hipSuccess;
     const int block = 256;
     const uint64_t grid = (n + block - 1) / block;
-    const size_t lds = (size_t)(depth - 1) * block * sizeof(uint2);
+    const size_t lds = (size_t)depth * block * sizeof(stack_t);
     if (!coef && !bias)
         hipLaunchKernelGGL(k_cast_rays_nolod, dim3((uint32_t)grid), dim3(block), lds, st, (const uint2*)nodes, depth, n, org, dir, out);
     else
@@ -1647,14 +1647,14 @@ hipError_t launch_render(const FrameArgs& a, uint32_t grid_blocks, int kernel, h
     const char* name = "";
     if (kernel == VRC_KERNEL_MIXED) {
         name = "k_render";
-        const size_t lds = (size_t)(a.depth - 1) * VRC_RENDER_BLOCK * sizeof(uint2) + 1536;
+        const size_t lds = (size_t)a.depth * VRC_RENDER_BLOCK * sizeof(stack_t) + 1536;
         hipLaunchKernelGGL(k_render, dim3(grid_blocks), dim3(VRC_RENDER_BLOCK), lds, st, a);
     } else if (kernel == VRC_KERNEL_TILE) {
         name = "k_render_tile";
-        const size_t lds = (size_t)(a.depth - 1) * VRC_RENDER_BLOCK * sizeof(uint2) + 4 * TILE_WAVE_LDS + 1536;
+        const size_t lds = (size_t)a.depth * VRC_RENDER_BLOCK * sizeof(stack_t) + 4 * TILE_WAVE_LDS + 1536;
         hipLaunchKernelGGL(k_render_tile, dim3(grid_blocks), dim3(VRC_RENDER_BLOCK), lds, st, a);
     } else {
-        const size_t lds = (size_t)(a.depth - 1) * VRC_RENDER_BLOCK * sizeof(uint2) + 1536 + 128;   // + the waves' counters
+        const size_t lds = (size_t)a.depth * VRC_RENDER_BLOCK * sizeof(stack_t) + 1536 + 128;   // + the waves' counters
         const bool pinhole = camera_is_pinhole(a.cam);
         const bool one = a.p.gi_bounces <= 1u, fused = a.fused_resolve != 0u;
         const uint32_t waves = a.waves;

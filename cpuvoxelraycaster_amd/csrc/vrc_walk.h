@@ -9,7 +9,7 @@
 //
 // Same arithmetic, same order, same rounding as ray_step (no FMA, IEEE mul / add / min):
 //   header   c = p * t_coef - t_offset; tc = min3(c); child / span / LOD / leaf tests      (:74-95)
-//   descend  push, parent += offset + shift, half, child select, t_max = min(t_max, tc)    (:96-111)
+//   descend  push, parent += offset + shift, half, child select                            (:96-111)
 //   advance  step mask, p -= step, t_min = tc, child ^= mask                                (:113-122)
 //   pop      differing bits -> scale, stack read, p &= ~0 << scale, child bits              (:124-145)
 // Exits: LOD cut (kind 2), leaf (kind 1), root left (miss), iteration cap (miss).
@@ -27,9 +27,9 @@
 // second resource (one per CU, ~1 instruction per cycle for four SIMDs): compares write EXEC directly (v_cmpx) instead of an
 // SGPR pair and an s_and.
 //
-// Register plan: ds_read_b64 / ds_write_b64 move the stack entry {parent_id, t_max} as one register pair and the node load
-// returns a pair; inline asm cannot name the halves of a 64-bit operand, so those four live in fixed registers (v42:43,
-// v46:47); everything else is allocated by the compiler.  Seven scratch registers serve all four blocks (the kernels are at
+// Register plan: the node load returns a register pair and inline asm cannot name the halves of a 64-bit operand, so the
+// node lives in fixed registers (v46:47); everything else is allocated by the compiler.  The stack entry is the parent index
+// alone (ray_step in vrc_device.h says why t_max need not be kept): rows of 256 lanes x 4 bytes.  Seven scratch registers serve all four blocks (the kernels are at
 // their register budget): `kind`, the result, is child_shift inside the loop; descend computes its half-points in m, t, t2
 // once the header is done with them; the advance keeps its steps in kind, m, t2 for the pop.  Every read-write operand is early-clobber ("+&v"): without it the
 // compiler may give an INPUT that happens to hold the same value (coef = 0.5 and the initial scale_f = 0.5) the same register,
@@ -65,14 +65,13 @@ __device__ __forceinline__ walk_rsrc_t walk_node_rsrc(const uint2* __restrict__ 
 // Without a LOD test: t_min <= min(t_max, tc) in one min and one compare (:81 is implied, see ray_step).
 #define VRC_WALK_SPAN_NOLOD                                                                     \
     "v_cmpx_ne_u32_e32 vcc, 0, %[t]\n"          /* :81 child exists */                          \
-    "v_min_f32_e32 %[t2], v43, %[tc]\n"         /* :86 tv_max */                                \
+    "v_min_f32_e32 %[t2], 1.0, %[tc]\n"         /* :86 tv_max = min(t_max, tc) = min(1, tc) */  \
     "v_cmpx_le_f32_e32 vcc, %[tmin], %[t2]\n"   /* :81,:89 */
-#define VRC_WALK_TMAX_NOLOD "v_mov_b32_e32 v43, %[t2]\n"
 // With it (LOD_MODE 1: bias == 0, x + 0 does not change the comparison; 2: general): :81 guards :82, so t_min <= t_max is
 // a compare of its own; with it, t_min <= tc is :89.
 #define VRC_WALK_SPAN_LOD(BIASPART)                                                             \
     "v_cmpx_ne_u32_e32 vcc, 0, %[t]\n"          /* :81 child exists */                          \
-    "v_cmpx_le_f32_e32 vcc, %[tmin], v43\n"     /* :81 t_min <= t_max */                        \
+    "v_cmpx_le_f32_e32 vcc, %[tmin], %[tmax]\n" /* :81 t_min <= t_max (= min(1, exit of the root)) */ \
     "v_mul_f32_e32 %[t2], %[coef], %[tc]\n"                                                     \
     BIASPART                                                                                    \
     "v_cmp_ge_f32_e32 vcc, %[t2], %[sf]\n"      /* :82 tc * coef + bias >= scale_f */           \
@@ -82,16 +81,15 @@ __device__ __forceinline__ walk_rsrc_t walk_node_rsrc(const uint2* __restrict__ 
     "v_cmpx_le_f32_e32 vcc, %[tmin], %[tc]\n"   /* :89 */
 #define VRC_WALK_BIAS_NONE ""
 #define VRC_WALK_BIAS_ADD "v_add_f32_e32 %[t2], %[t2], %[bias]\n"
-#define VRC_WALK_TMAX_LOD "v_min_f32_e32 v43, v43, %[tc]\n"
 
 #ifdef VRC_WALK_GLOBAL_LOAD   /* A/B: the byte offset computed by the VALU */
-#define VRC_WALK_LOAD_NODE "v_lshlrev_b32_e32 %[m], 3, v42\n global_load_dwordx2 v[46:47], %[m], %[nodes]\n"
+#define VRC_WALK_LOAD_NODE "v_lshlrev_b32_e32 %[m], 3, %[pid]\n global_load_dwordx2 v[46:47], %[m], %[nodes]\n"
 #else
-#define VRC_WALK_LOAD_NODE "buffer_load_dwordx2 v[46:47], v42, %[rsrc], 0 idxen\n"
+#define VRC_WALK_LOAD_NODE "buffer_load_dwordx2 v[46:47], %[pid], %[rsrc], 0 idxen\n"
 #endif
 
-// v42:43 {parent_id, t_max} (the stack entry)   v46:47 node
-#define VRC_WALK_ASM(SPANPART, TMAXPART, COUNTPART)                                             \
+// v46:47 node
+#define VRC_WALK_ASM(SPANPART, COUNTPART)                                                       \
     "s_mov_b64 %[sentry], exec\n"                                                               \
     "s_and_b64 exec, exec, %[sact]\n"           /* the lanes with a ray to walk */              \
     "s_mov_b64 %[sleaf], 0\n"                                                                   \
@@ -124,13 +122,12 @@ __device__ __forceinline__ walk_rsrc_t walk_node_rsrc(const uint2* __restrict__ 
     "s_cbranch_scc0 Lwalk_adv%=\n"                                                              \
     /* ---- descend :96-111 ---- */                                                             \
     /* :97-100 the push is unconditional: `tc_max < h` only skips writes of what the slot already holds (the level's    \
-       {parent, t_max} do not change while the walk is below it) or of entries that are never read (last child on the   \
-       ray); h is not kept at all */                                                            \
-    "ds_write_b64 %[sp], v[42:43]\n"                                                            \
+       parent does not change while the walk is below it) or of entries that are never read (last child on the ray); h  \
+       is not kept at all */                                                                    \
+    "ds_write_b32 %[sp], %[pid]\n"                                                              \
     "v_mul_f32_e32 %[sf], 0.5, %[sf]\n"         /* :87 half, becomes scale_f :105 */            \
-    "v_add3_u32 v42, v42, v47, %[kind]\n"         /* :103 */                                      \
+    "v_add3_u32 %[pid], %[pid], v47, %[kind]\n"   /* :103 */                                      \
     VRC_WALK_LOAD_NODE                                                                          \
-    TMAXPART                                    /* :110 t_max = tv_max (t2 is free after it) */ \
     /* h = half * t_coef + c (:88) in the header's scratch registers: m, t, t2 */               \
     "v_mul_f32_e32 %[m], %[tcx], %[sf]\n"                                                       \
     "v_mul_f32_e32 %[t], %[tcy], %[sf]\n"                                                       \
@@ -143,7 +140,7 @@ __device__ __forceinline__ walk_rsrc_t walk_node_rsrc(const uint2* __restrict__ 
     "v_sub_f32_e32 %[m], %[tmin], %[m]\n"                                                       \
     "v_sub_f32_e32 %[t], %[tmin], %[t]\n"                                                       \
     "v_sub_f32_e32 %[t2], %[tmin], %[t2]\n"                                                     \
-    "v_add_u32_e32 %[sp], 0xfffff800, %[sp]\n"  /* :104 --scale: the next stack row down */     \
+    "v_add_u32_e32 %[sp], 0xfffffc00, %[sp]\n"  /* :104 --scale: the next stack row down */     \
     "v_ashrrev_i32_e32 %[m], 31, %[m]\n"                                                        \
     "v_ashrrev_i32_e32 %[t], 31, %[t]\n"                                                        \
     "v_ashrrev_i32_e32 %[t2], 31, %[t2]\n"                                                      \
@@ -191,8 +188,8 @@ __device__ __forceinline__ walk_rsrc_t walk_node_rsrc(const uint2* __restrict__ 
     "s_andn2_b64 %[srun], %[srun], vcc\n"                                                       \
     "s_andn2_b64 exec, exec, vcc\n"                                                             \
     "s_cbranch_scc0 Lwalk_next%=\n"                                                             \
-    "v_lshl_add_u32 %[sp], %[t], 11, %[stkb]\n"                                                 \
-    "ds_read_b64 v[42:43], %[sp]\n"             /* :134-136 */                                  \
+    "v_lshl_add_u32 %[sp], %[t], 10, %[stkb]\n"                                                 \
+    "ds_read_b32 %[pid], %[sp]\n"               /* :134-136 */                                  \
     "v_lshl_add_u32 %[sf], %[t], 23, %[sfc]\n"  /* :133 2^(scale-23) */                         \
     "v_lshlrev_b32_e64 %[t2], %[t], -1\n"       /* (the steps in cs, m, t2 are dead by now) */  \
     "v_bfe_u32 %[cx], %[px], %[t], 1\n"         /* :137-143 */                                  \
@@ -210,63 +207,66 @@ __device__ __forceinline__ walk_rsrc_t walk_node_rsrc(const uint2* __restrict__ 
     "s_cbranch_execnz Lwalk_loop%=\n"                                                           \
     "Lwalk_done%=:\n"                                                                           \
     "s_waitcnt vmcnt(0) lgkmcnt(0)\n"                                                           \
+    "s_and_b64 exec, %[sentry], %[sact]\n"                                                      \
+    "ds_write_b32 %[sp], %[pid]\n"              /* the parent of the hit in the row of its scale: with the rows above it, \
+                                                   the path from the root (a ray that starts next to the hit reads it) */ \
     "s_mov_b64 exec, %[sentry]\n"                                                               \
     "v_cndmask_b32_e64 %[kind], 0, 1, %[sleaf]\n"                                               \
     "v_cndmask_b32_e64 %[kind], %[kind], 2, %[slod]\n"
 
 // Runs the walk for the lanes with `active` set (the others keep their state: kind 0, complexity 0).
-// `stk` = this lane's column of the LDS stack, rows of 256 lanes (2 KiB apart).
+// `stk` = this lane's column of the LDS stack, `depth` rows of 256 lanes (1 KiB apart).
 // COUNT_LANE: r.complexity is maintained (per lane); otherwise it is left alone and the return value is the number of
 // loop iterations all the wave's lanes executed in this call together (the same value in every lane that made the call).
 // r.h is not maintained (see the push above); nothing reads it after a walk.
 template <int LOD_MODE, bool COUNT_LANE>
-__device__ __forceinline__ uint32_t ray_walk(Ray& r, bool active, const uint2* __restrict__ nodes, uint2* stk,
+__device__ __forceinline__ uint32_t ray_walk(Ray& r, bool active, const uint2* __restrict__ nodes, stack_t* stk,
                                              int depth, float coef, float bias)
 {
     // (no branch around the loop for the lanes without a ray: the loop masks them itself, so that the SGPR results
     // are the same for every lane that made the call)
     const unsigned long long sact = __ballot(active);
-    // LDS byte address of slot 0 minus the rows of the scales that have no slot (slot = scale - depth_off - 1)
-    const uint32_t stkb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint2*)stk
-                          - (uint32_t)(SVO_MAX - depth + 1) * 2048u;
+    // LDS byte address of slot 0 minus the rows of the scales that have no slot (slot = scale - depth_off)
+    const uint32_t stkb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) stack_t*)stk
+                          - (uint32_t)(SVO_MAX - depth) * 1024u;
     const uint32_t sfc = 104u << 23;            // (scale - 23 + 127) << 23 = (scale << 23) + (104 << 23)
     const walk_rsrc_t rsrc = walk_node_rsrc(nodes);
     uint64_t sentry, sleaf, slod, srun, sin_, sx, sy, st;   // sx / sy: the x / y step masks of the advance
     uint32_t siter, m, t, t2, kind, ssteps = 0u, sb;
     float tc, cx, cy, cz;
-    float px = r.px, py = r.py, pz = r.pz, t_min = r.t_min, t_max = r.t_max, sf = r.scale_f;
+    float px = r.px, py = r.py, pz = r.pz, t_min = r.t_min, sf = r.scale_f;
     uint32_t pid = r.parent_id, ndx = r.nd.x, ndy = r.nd.y;
-    uint32_t sp = stkb + ((uint32_t)r.scale << 11);          // the level, as the LDS address of its stack row
+    uint32_t sp = stkb + ((uint32_t)r.scale << 10);          // the level, as the LDS address of its stack row
     uint32_t co = r.child_offset, normal = r.normal, cmpl = COUNT_LANE ? r.complexity : 0u;
 #define VRC_WALK_OPERANDS(COUNT_OPERANDS)                                                                         \
         : [kind] "=&v"(kind), COUNT_OPERANDS, [sp] "+&v"(sp), [co] "+&v"(co), [normal] "+&v"(normal),                     \
-          [px] "+&v"(px), [py] "+&v"(py), [pz] "+&v"(pz), [tmin] "+&v"(t_min), "+{v42}"(pid), "+{v43}"(t_max),            \
+          [px] "+&v"(px), [py] "+&v"(py), [pz] "+&v"(pz), [tmin] "+&v"(t_min), [pid] "+&v"(pid),                          \
           [sf] "+&v"(sf), "+{v46}"(ndx), "+{v47}"(ndy),                                                                \
           [sentry] "=&s"(sentry), [sleaf] "=&s"(sleaf), [slod] "=&s"(slod), [srun] "=&s"(srun), [sin] "=&s"(sin_),    \
           [sx] "=&s"(sx), [sy] "=&s"(sy), [st] "=&s"(st),                                                             \
           [siter] "=&s"(siter), [m] "=&v"(m), [t] "=&v"(t), [t2] "=&v"(t2), [tc] "=&v"(tc),                           \
           [cx] "=&v"(cx), [cy] "=&v"(cy), [cz] "=&v"(cz)                                                              \
         : [tcx] "v"(r.tcx), [tcy] "v"(r.tcy), [tcz] "v"(r.tcz), [tox] "v"(r.tox), [toy] "v"(r.toy), [toz] "v"(r.toz), \
-          [mirror] "v"(r.mirror), [stkb] "v"(stkb), [rsrc] "s"(rsrc), [nodes] "s"(nodes), [sfc] "s"(sfc), [coef] "v"(coef), [bias] "v"(bias), \
+          [mirror] "v"(r.mirror), [stkb] "v"(stkb), [rsrc] "s"(rsrc), [nodes] "s"(nodes), [sfc] "s"(sfc), [coef] "v"(coef), [bias] "v"(bias), [tmax] "v"(r.t_max), \
           [sact] "s"(sact)                                                                                             \
         : "vcc", "scc", "memory"
 #define VRC_WALK_OPS_LANE [cmpl] "+&v"(cmpl)
 #define VRC_WALK_OPS_WAVE [ssteps] "+&s"(ssteps), [sb] "=&s"(sb)
     if (COUNT_LANE) {
-        if (LOD_MODE == 0) asm volatile(VRC_WALK_ASM(VRC_WALK_SPAN_NOLOD, VRC_WALK_TMAX_NOLOD, VRC_WALK_COUNT_LANE) VRC_WALK_OPERANDS(VRC_WALK_OPS_LANE));
-        else if (LOD_MODE == 1) asm volatile(VRC_WALK_ASM(VRC_WALK_SPAN_LOD(VRC_WALK_BIAS_NONE), VRC_WALK_TMAX_LOD, VRC_WALK_COUNT_LANE) VRC_WALK_OPERANDS(VRC_WALK_OPS_LANE));
-        else asm volatile(VRC_WALK_ASM(VRC_WALK_SPAN_LOD(VRC_WALK_BIAS_ADD), VRC_WALK_TMAX_LOD, VRC_WALK_COUNT_LANE) VRC_WALK_OPERANDS(VRC_WALK_OPS_LANE));
+        if (LOD_MODE == 0) asm volatile(VRC_WALK_ASM(VRC_WALK_SPAN_NOLOD, VRC_WALK_COUNT_LANE) VRC_WALK_OPERANDS(VRC_WALK_OPS_LANE));
+        else if (LOD_MODE == 1) asm volatile(VRC_WALK_ASM(VRC_WALK_SPAN_LOD(VRC_WALK_BIAS_NONE), VRC_WALK_COUNT_LANE) VRC_WALK_OPERANDS(VRC_WALK_OPS_LANE));
+        else asm volatile(VRC_WALK_ASM(VRC_WALK_SPAN_LOD(VRC_WALK_BIAS_ADD), VRC_WALK_COUNT_LANE) VRC_WALK_OPERANDS(VRC_WALK_OPS_LANE));
     } else {
-        if (LOD_MODE == 0) asm volatile(VRC_WALK_ASM(VRC_WALK_SPAN_NOLOD, VRC_WALK_TMAX_NOLOD, VRC_WALK_COUNT_WAVE) VRC_WALK_OPERANDS(VRC_WALK_OPS_WAVE));
-        else if (LOD_MODE == 1) asm volatile(VRC_WALK_ASM(VRC_WALK_SPAN_LOD(VRC_WALK_BIAS_NONE), VRC_WALK_TMAX_LOD, VRC_WALK_COUNT_WAVE) VRC_WALK_OPERANDS(VRC_WALK_OPS_WAVE));
-        else asm volatile(VRC_WALK_ASM(VRC_WALK_SPAN_LOD(VRC_WALK_BIAS_ADD), VRC_WALK_TMAX_LOD, VRC_WALK_COUNT_WAVE) VRC_WALK_OPERANDS(VRC_WALK_OPS_WAVE));
+        if (LOD_MODE == 0) asm volatile(VRC_WALK_ASM(VRC_WALK_SPAN_NOLOD, VRC_WALK_COUNT_WAVE) VRC_WALK_OPERANDS(VRC_WALK_OPS_WAVE));
+        else if (LOD_MODE == 1) asm volatile(VRC_WALK_ASM(VRC_WALK_SPAN_LOD(VRC_WALK_BIAS_NONE), VRC_WALK_COUNT_WAVE) VRC_WALK_OPERANDS(VRC_WALK_OPS_WAVE));
+        else asm volatile(VRC_WALK_ASM(VRC_WALK_SPAN_LOD(VRC_WALK_BIAS_ADD), VRC_WALK_COUNT_WAVE) VRC_WALK_OPERANDS(VRC_WALK_OPS_WAVE));
     }
 #undef VRC_WALK_OPS_LANE
 #undef VRC_WALK_OPS_WAVE
 #undef VRC_WALK_OPERANDS
-    r.px = px; r.py = py; r.pz = pz; r.t_min = t_min; r.t_max = t_max; r.scale_f = sf;
+    r.px = px; r.py = py; r.pz = pz; r.t_min = t_min; r.scale_f = sf;
     r.parent_id = pid; r.nd = make_uint2(ndx, ndy);
-    r.scale = (int)((sp - stkb) >> 11); r.child_offset = co; r.normal = normal;
+    r.scale = (int)((sp - stkb) >> 10); r.child_offset = co; r.normal = normal;
     if (COUNT_LANE) r.complexity = cmpl;
     r.kind = kind;                              // 0 for a lane without a ray, as ray_setup left it
     r.shift = co ^ r.mirror;                    // child_shift of the child that was hit (unused on a miss)

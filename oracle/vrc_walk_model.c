@@ -1,0 +1,196 @@
+/*
+ * vrc_walk_model.c -- CPU model of the FORMULATION the HIP walk uses (cpuvoxelraycaster_amd/csrc/vrc_walk.h), to check that
+ * formulation against the oracle (oracle/vrc_oracle.c, which follows the reference line by line) ray by ray, here, without a
+ * GPU.  TEST INFRASTRUCTURE ONLY (tests/test_walk_model.py); the product never links it.
+ *
+ * The reference is LSVO<N>::castRay, /root/reference/include/lsvo.hpp:33-172.  What the HIP walk does differently, and what
+ * this model therefore restates:
+ *
+ * 1. No t_max on the stack.  The reference keeps {parent_index, t_max} per level (:97-100, :134-136).  t_max is always
+ *    min(1, exit(parent cell)): :57-58 set it so for the root, :110 keeps it (t_max' = min(t_max, tc_max), and tc_max, the exit
+ *    of the child cell, is never larger than the exit of the cell around it -- x -> x * t_coef - t_offset is monotone in
+ *    float arithmetic too and a child's corner is never below its parent's), :134-136 restore it.  Hence
+ *      tv_max (:86)            = min(t_max, tc_max) = min(1, tc_max)
+ *      t_min <= t_max (:81)    = t_min <= T1 with the per-ray constant T1 = min(1, exit(root)): inside the cube
+ *                                t_min (the exit of a cell inside the parent) never exceeds the parent's exit.
+ *    The stack holds parent indices only, pushed on every descend.
+ *
+ * 2. Start below the root.  A secondary ray starts next to the hit of the ray before it (raycaster.hpp:139,153; :171-176,
+ *    :195-198).  Its first iterations are pure descends from the root to the cell that holds its origin: child present and
+ *    not a leaf (the previous walk went through the same nodes), t_min = 0 <= exits, the child chosen at :66-68 / :107-109 is
+ *    the one that holds the origin.  The model (and the kernel) starts the ray at scale s0 with exactly the state those
+ *    22 - s0 iterations produce -- parent from the previous walk's stack, pos = origin bits above s0, complexity 22 - s0 --
+ *    provided every comparison of the skipped iterations is decided with a margin:
+ *      - both origin and previous hit position are in [1, 2) and agree in all bits above s0 (same cells down to the parent),
+ *      - s0 >= scale of the previous hit (those parents are on the stack),
+ *      - no multiple of 2^s0 ulps lies within 8 ulps of an origin coordinate (the centre planes the skipped comparisons
+ *        test; their rounding error is below 4.5 ulps of the coordinate),
+ *      - LOD test (:82) cannot fire in a cell that holds the origin when coef <= 0.5, bias = 0 and |d| = 1 (caller's
+ *        promise: tc_max <= sqrt(3) * scale_f there).
+ *    Otherwise the ray starts at the root as in the reference.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "vrc_oracle.h"
+
+#ifndef ORC_MARGIN
+#define ORC_MARGIN 8u     /* ulps; the comparisons of the skipped iterations are exact beyond 4.5 */
+#endif
+
+typedef struct orc_walk_state {
+    uint32_t rows[24];      /* parent index by scale (the LDS stack column of a lane) */
+    uint32_t scale;         /* scale of the hit child; rows[scale] = the hit's parent */
+    uint32_t valid;         /* the walk ended in a hit */
+} orc_walk_state;
+
+static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float smin(float a, float b) { return b < a ? b : a; }
+static inline float smax(float a, float b) { return a < b ? b : a; }
+static inline float gsign(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : x); }
+static inline float frac_(float x) { return x - floorf(x); }
+static inline int highbit(uint32_t x) { return x ? 31 - __builtin_clz(x) : -1; }
+
+/* One ray.  prev / prev_pos: state and hit position of the ray this one starts next to (NULL: start at the root).
+ * *skipped = iterations not executed (already part of out->complexity). */
+void orc_model_cast(const orc_lnode *raw, uint32_t depth, const float org[3], const float dir[3], float coef, float bias,
+                    const orc_walk_state *prev, const float prev_pos[3], orc_hit *out, orc_walk_state *st, uint32_t *skipped)
+{
+    memset(out, 0, sizeof(*out));
+    memset(st, 0, sizeof(*st));
+    *skipped = 0;
+    const int SVO_MAX = 23;
+    const float EPS = 1.0f / (float)(1 << 23);
+    const float px = org[0], py = org[1], pz = org[2];
+    float dx = dir[0], dy = dir[1], dz = dir[2];
+    if (!isfinite(px) || !isfinite(py) || !isfinite(pz) || !isfinite(dx) || !isfinite(dy) || !isfinite(dz)) return;
+    if (fabsf(dx) < EPS) dx = copysignf(EPS, dx);
+    if (fabsf(dy) < EPS) dy = copysignf(EPS, dy);
+    if (fabsf(dz) < EPS) dz = copysignf(EPS, dz);
+    const float tcx = -1.0f / fabsf(dx), tcy = -1.0f / fabsf(dy), tcz = -1.0f / fabsf(dz);
+    float tox = px * tcx, toy = py * tcy, toz = pz * tcz;
+    uint32_t mirror = 7u;
+    if (dx > 0.0f) { mirror ^= 1u; tox = 3.0f * tcx - tox; }
+    if (dy > 0.0f) { mirror ^= 2u; toy = 3.0f * tcy - toy; }
+    if (dz > 0.0f) { mirror ^= 4u; toz = 3.0f * tcz - toz; }
+    float t_min = smax(2.0f * tcx - tox, smax(2.0f * tcy - toy, 2.0f * tcz - toz));
+    t_min = smax(0.0f, t_min);
+    const float T1 = smin(1.0f, smin(tcx - tox, smin(tcy - toy, tcz - toz)));
+    uint32_t parent = 0u, co = 0u, scale = 22u, complexity = 0u, normal = 0u;
+    float posx = 1.0f, posy = 1.0f, posz = 1.0f, sf = 0.5f;
+    if (1.5f * tcx - tox > t_min) { co ^= 1u; posx = 1.5f; }
+    if (1.5f * tcy - toy > t_min) { co ^= 2u; posy = 1.5f; }
+    if (1.5f * tcz - toz > t_min) { co ^= 4u; posz = 1.5f; }
+    uint32_t rows[24];
+    memset(rows, 0, sizeof(rows));
+
+    if (prev && prev->valid) {
+        const uint32_t ob[3] = { f2u(px), f2u(py), f2u(pz) };
+        const uint32_t hb[3] = { f2u(prev_pos[0]), f2u(prev_pos[1]), f2u(prev_pos[2]) };
+        uint32_t db = 0u, mb = 0u;
+        for (int i = 0; i < 3; i++) { db |= ob[i] ^ hb[i]; mb |= (ob[i] - ORC_MARGIN) ^ (ob[i] + ORC_MARGIN); }
+        int s0 = highbit(db | (mb + mb));
+        if (s0 < (int)prev->scale) s0 = (int)prev->scale;
+        if (s0 < 22) {
+            /* the state of a pop to scale s0 with pos = the mirrored origin (lsvo.hpp:133-143) */
+            const float mx = (mirror & 1u) ? px : 3.0f - px, my = (mirror & 2u) ? py : 3.0f - py, mz = (mirror & 4u) ? pz : 3.0f - pz;
+            const uint32_t keep = 0xffffffffu << s0;
+            posx = u2f(f2u(mx) & keep); posy = u2f(f2u(my) & keep); posz = u2f(f2u(mz) & keep);
+            co = ((f2u(mx) >> s0) & 1u) | (((f2u(my) >> s0) & 1u) << 1) | (((f2u(mz) >> s0) & 1u) << 2);
+            scale = (uint32_t)s0;
+            sf = u2f((uint32_t)(s0 - SVO_MAX + 127) << 23);
+            memcpy(rows, prev->rows, sizeof(rows));
+            parent = rows[s0];
+            complexity = 22u - (uint32_t)s0;
+            *skipped = complexity;
+        }
+    }
+
+    uint32_t kind = 0u, shift = 0u;
+    while (scale < 23u) {
+        if (complexity >= 65536u) break;
+        ++complexity;
+        const orc_lnode nd = raw[parent];
+        const float cx = posx * tcx - tox, cy = posy * tcy - toy, cz = posz * tcz - toz;
+        const float tc = smin(cx, smin(cy, cz));
+        const uint32_t cs = co ^ mirror;
+        const int child = (nd.child_mask >> cs) & 1;
+        int inside;
+        if (coef != 0.0f || bias != 0.0f) {
+            inside = child && t_min <= T1;
+            if (inside && tc * coef + bias >= sf) { kind = 2u; shift = cs; break; }
+            inside = inside && t_min <= tc;
+        } else {
+            inside = child && t_min <= smin(1.0f, tc);
+        }
+        if (inside) {
+            if ((nd.leaf_mask >> cs) & 1) { kind = 1u; shift = cs; break; }
+            const float half = sf * 0.5f;
+            const float thx = half * tcx + cx, thy = half * tcy + cy, thz = half * tcz + cz;
+            rows[scale] = parent;
+            parent += nd.child_offset + cs;
+            co = 0u; --scale; sf = half;
+            if (thx > t_min) { co ^= 1u; posx += sf; }
+            if (thy > t_min) { co ^= 2u; posy += sf; }
+            if (thz > t_min) { co ^= 4u; posz += sf; }
+            continue;
+        }
+        uint32_t step = 0u;
+        const uint32_t opx = f2u(posx), opy = f2u(posy), opz = f2u(posz);
+        if (cx <= tc) { step ^= 1u; posx -= sf; }
+        if (cy <= tc) { step ^= 2u; posy -= sf; }
+        if (cz <= tc) { step ^= 4u; posz -= sf; }
+        t_min = tc;
+        co ^= step;
+        normal = step;
+        if (co & step) {
+            const uint32_t ipx = f2u(posx), ipy = f2u(posy), ipz = f2u(posz);
+            const uint32_t diff = (ipx ^ opx) | (ipy ^ opy) | (ipz ^ opz);
+            const int s = highbit(diff);
+            if (s < 0 || s >= SVO_MAX) { scale = 23u; break; }
+            scale = (uint32_t)s;
+            sf = u2f((uint32_t)(s - SVO_MAX + 127) << 23);
+            parent = rows[scale];
+            const uint32_t keep = 0xffffffffu << scale;
+            posx = u2f(ipx & keep); posy = u2f(ipy & keep); posz = u2f(ipz & keep);
+            co = ((ipx >> scale) & 1u) | (((ipy >> scale) & 1u) << 1) | (((ipz >> scale) & 1u) << 2);
+        }
+    }
+    out->complexity = complexity;
+    if (kind) {
+        out->normal[0] = -gsign(dx) * (float)(normal & 1u);
+        out->normal[1] = -gsign(dy) * (float)(normal & 2u);
+        out->normal[2] = -gsign(dz) * (float)(normal & 4u);
+        if ((mirror & 1u) == 0u) posx = 3.0f - sf - posx;
+        if ((mirror & 2u) == 0u) posy = 3.0f - sf - posy;
+        if ((mirror & 4u) == 0u) posz = 3.0f - sf - posz;
+        out->distance = t_min;
+        out->position[0] = smin(smax(px + t_min * dx, posx + EPS), posx + sf - EPS);
+        out->position[1] = smin(smax(py + t_min * dy, posy + EPS), posy + sf - EPS);
+        out->position[2] = smin(smax(pz + t_min * dz, posz + EPS), posz + sf - EPS);
+        const float S = (float)(1u << depth);
+        if (out->normal[0]) { out->voxel_coord[0] = frac_(out->position[2] * S); out->voxel_coord[1] = frac_(out->position[1] * S); }
+        else if (out->normal[1]) { out->voxel_coord[0] = frac_(out->position[0] * S); out->voxel_coord[1] = frac_(out->position[2] * S); }
+        else if (out->normal[2]) { out->voxel_coord[0] = frac_(out->position[0] * S); out->voxel_coord[1] = frac_(out->position[1] * S); }
+        out->hit = kind | (shift << 8) | ((scale & 0xffu) << 16);
+        out->node = parent;
+        rows[scale] = parent;
+        memcpy(st->rows, rows, sizeof(rows));
+        st->scale = scale;
+        st->valid = 1u;
+    }
+}
+
+/* n independent chains: ray i starts next to hit i of the previous call (prev / prev_pos NULL: from the root) */
+void orc_model_cast_rays(const orc_lnode *raw, uint32_t depth, uint64_t n, const float *org, const float *dir,
+                         float coef, float bias, const orc_walk_state *prev, const float *prev_pos,
+                         orc_hit *out, orc_walk_state *st, uint32_t *skipped, int threads)
+{
+    if (threads < 1) threads = 1;
+#pragma omp parallel for schedule(dynamic, 1024) num_threads(threads)
+    for (int64_t i = 0; i < (int64_t)n; i++)
+        orc_model_cast(raw, depth, org + 3 * i, dir + 3 * i, coef, bias, prev ? prev + i : 0, prev_pos ? prev_pos + 3 * i : 0,
+                       out + i, st + i, skipped + i);
+}

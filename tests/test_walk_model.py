@@ -1,0 +1,144 @@
+"""The formulation of the HIP walk (csrc/vrc_walk.h) checked against the oracle on the CPU, ray by ray, on chains of rays shaped
+like the ones a frame casts (raycaster.hpp:118-207): primary -> shadow ray from its hit, GI ray from its hit -> GI shadow ray.
+
+oracle/vrc_walk_model.c restates what the kernel does differently from lsvo.hpp:33-172 -- no t_max on the stack (it is always
+min(1, exit of the parent cell)) and secondary rays that start at the deepest ancestor they share with the previous hit instead
+of at the root -- and must return the oracle's hit, bit for bit, with the oracle's iteration count (skipped iterations
+included)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+STATE_DTYPE = np.dtype([("rows", "<u4", 24), ("scale", "<u4"), ("valid", "<u4")])
+
+
+def model_lib():
+    path = os.path.join(O.ORACLE_DIR, "libvrc_walk_model.so")
+    src = os.path.join(O.ORACLE_DIR, "vrc_walk_model.c")
+    if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", O.ORACLE_DIR, "libvrc_walk_model.so"], stdout=subprocess.DEVNULL)
+    L = C.CDLL(path)
+    vp = C.c_void_p
+    L.orc_model_cast_rays.argtypes = [vp, C.c_uint32, C.c_uint64, vp, vp, C.c_float, C.c_float, vp, vp, vp, vp, vp, C.c_int]
+    return L
+
+
+def model_cast(L, nodes, depth, org, dir_, coef, prev=None, prev_pos=None, threads=8):
+    n = len(org)
+    org = np.ascontiguousarray(org, np.float32)
+    dir_ = np.ascontiguousarray(dir_, np.float32)
+    out = np.zeros(n, O.HIT_DTYPE)
+    st = np.zeros(n, STATE_DTYPE)
+    skipped = np.zeros(n, np.uint32)
+    pp = np.ascontiguousarray(prev_pos, np.float32) if prev_pos is not None else None
+    L.orc_model_cast_rays(O._ptr(nodes), depth, n, O._ptr(org), O._ptr(dir_), coef, 0.0,
+                          O._ptr(prev) if prev is not None else None, O._ptr(pp) if pp is not None else None,
+                          O._ptr(out), O._ptr(st), O._ptr(skipped), threads)
+    return out, st, skipped
+
+
+def normalize(v):
+    v = v.astype(np.float32)
+    n = np.sqrt((v * v).sum(axis=1, dtype=np.float32)).astype(np.float32)
+    return (v / n[:, None]).astype(np.float32)
+
+
+def same(a, b):
+    return a.tobytes() == b.tobytes()
+
+
+def chains(nodes, depth, org, dir_, light, rng, L):
+    """returns the number of rays compared and the iterations skipped / executed by the secondary rays"""
+    f = np.float32
+    inv = f(1.0) / f(1 << depth)
+    nn = f(inv * f(0.0078125) * f(2.0))
+    ref = O.cast_rays(nodes, depth, org, dir_, 0.0, 0.0, threads=8)
+    mod, st, sk = model_cast(L, nodes, depth, org, dir_, 0.0)
+    assert same(ref, mod) and not sk.any()
+    hit = ref["hit"] != 0
+    assert hit.sum() > len(org) // 4
+    P, stP = ref[hit], np.ascontiguousarray(st[hit])
+    total, skipped, iters = len(org), 0, 0
+    # shadow ray: raycaster.hpp:139,151-153
+    so = (P["position"] + (P["normal"] * inv) * f(0.001)).astype(f)
+    sd = normalize(light[None, :] - so)
+    ref_s = O.cast_rays(nodes, depth, so, sd, 0.0, 0.0, threads=8)
+    mod_s, _, sk = model_cast(L, nodes, depth, so, sd, 0.0, stP, P["position"])
+    assert same(ref_s, mod_s)
+    total += len(so); skipped += int(sk.sum()); iters += int(ref_s["complexity"].sum())
+    # GI ray: :171-194, from the primary hit as well (here through the primary's stack; the kernel may start it at the root)
+    go = (P["position"] + P["normal"] * nn).astype(f)
+    noise = rng.uniform(-1000.0, 1000.0, (len(go), 3)).astype(f)
+    noise[P["normal"] != 0] = 0.0
+    gd = normalize((P["normal"] + noise) * nn)
+    ok = np.isfinite(gd).all(axis=1)
+    go, gd, stG, Pg = go[ok], gd[ok], np.ascontiguousarray(stP[ok]), P[ok]
+    ref_g = O.cast_rays(nodes, depth, go, gd, 0.5, 0.0, threads=8)
+    mod_g, st_g, sk = model_cast(L, nodes, depth, go, gd, 0.5, stG, Pg["position"])
+    assert same(ref_g, mod_g)
+    total += len(go); skipped += int(sk.sum()); iters += int(ref_g["complexity"].sum())
+    mod_g0, st_g0, sk0 = model_cast(L, nodes, depth, go, gd, 0.5)             # and from the root, as the kernel does
+    assert same(ref_g, mod_g0) and not sk0.any()
+    # GI shadow ray: :195-198 (LOD coefficient 0.5 as the reference passes it)
+    gh = ref_g["hit"] != 0
+    G, stGh = ref_g[gh], np.ascontiguousarray(st_g0[gh])
+    gso = (G["position"] + G["normal"] * nn).astype(f)
+    gsd = normalize(light[None, :] - gso)
+    ref_gs = O.cast_rays(nodes, depth, gso, gsd, 0.5, 0.0, threads=8)
+    mod_gs, _, sk = model_cast(L, nodes, depth, gso, gsd, 0.5, stGh, G["position"])
+    assert same(ref_gs, mod_gs)
+    total += len(gso); skipped += int(sk.sum()); iters += int(ref_gs["complexity"].sum())
+    return total, skipped, iters
+
+
+def camera_rays(n, depth, rng, pitch):
+    import cpuvoxelraycaster_amd as vrc
+    cam = vrc.reference_camera(depth, pitch=pitch, make_rotation=lambda x, y: O.make_rotation(x, y))
+    rot = np.asarray(cam.rot, np.float32).reshape(3, 3)
+    f = np.float32
+    lens = np.stack([rng.uniform(-0.89, 0.89, n), rng.uniform(-0.5, 0.5, n), np.full(n, cam.fov)], axis=1).astype(f)
+    d = normalize(lens) @ rot.T
+    inv = f(1.0) / f(1 << depth)
+    o = (np.asarray(cam.position, f) * inv + f(1.0)).astype(f)
+    return np.broadcast_to(o, (n, 3)).copy(), normalize(d)
+
+
+@pytest.mark.parametrize("depth,n", [(7, 120000), (9, 250000)])
+def test_model_equals_oracle_on_frame_like_chains(depth, n):
+    import cpuvoxelraycaster_amd as vrc
+    L = model_lib()
+    nodes = vrc.build_terrain_lsvo(O.load_terrain_heights(), depth)
+    rng = np.random.default_rng(depth)
+    light = np.asarray(vrc.reference_light(depth), np.float32)
+    total = skipped = iters = 0
+    for pitch in (-0.5, -1.2, 0.0):
+        org, dir_ = camera_rays(n, depth, rng, pitch)
+        t, s, i = chains(nodes, depth, org, dir_, light, rng, L)
+        total, skipped, iters = total + t, skipped + s, iters + i
+    assert skipped > 0.1 * iters            # the start below the root is taken, and for a large part of the iterations
+    print(f"depth {depth}: {total} rays; secondary rays: {skipped} of {iters} iterations not executed ({skipped / iters:.1%})")
+
+
+def test_model_equals_oracle_on_random_rays_and_edges():
+    """rays from anywhere (outside the cube, on cell boundaries, axis-parallel), chained to whatever they hit"""
+    import cpuvoxelraycaster_amd as vrc
+    L = model_lib()
+    depth = 6
+    nodes = vrc.build_terrain_lsvo(O.load_terrain_heights(), depth)
+    rng = np.random.default_rng(5)
+    n = 200000
+    f = np.float32
+    org = rng.uniform(0.9, 2.1, (n, 3)).astype(f)
+    grid = (np.round(org * 64.0) / 64.0).astype(f)
+    org[: n // 4] = grid[: n // 4]                                            # on cell boundaries
+    org[n // 4: n // 2, 1] = grid[n // 4: n // 2, 1]
+    dir_ = normalize(rng.normal(size=(n, 3)))
+    dir_[::7, 0] = 0.0
+    dir_[::11, 2] = -0.0
+    light = np.asarray(vrc.reference_light(depth), f)
+    chains(nodes, depth, org, normalize(dir_ + f(0.0)), light, rng, L)
