@@ -298,15 +298,16 @@ __device__ __forceinline__ bool ray_step(Ray& r, const uint2* __restrict__ nodes
 namespace vrc {
 
 // The whole walk of one ray.  LOD_MODE: 0 = coef == bias == 0 (primary / shadow rays), 1 = bias == 0, 2 = general.
-template <int STRIDE, int LOD_MODE>
+template <int STRIDE, int LOD_MODE, bool BELOW = false>   // BELOW: the ray may start below the root (ray_start_below, further down)
 __device__ __forceinline__ void ray_run(Ray& r, bool active, const uint2* __restrict__ nodes, stack_t* stk,
                                         int depth, float coef, float bias)
 {
 #ifdef VRC_WALK_CPP
     while (active) active = ray_step<STRIDE, LOD_MODE != 0>(r, nodes, stk, depth, coef, bias);
 #else
-    static_assert(STRIDE == 256, "vrc_walk.h addresses LDS stack rows of 256 lanes");
-    ray_walk<LOD_MODE, true>(r, active, nodes, stk, depth, coef, bias);
+    static_assert(STRIDE == 256 || STRIDE == 512, "vrc_walk.h addresses LDS stack rows of 256 lanes, 1 or 2 KiB apart");
+    if (BELOW && active) r.complexity = (uint32_t)(SVO_MAX - 1 - r.scale);       // :73 for the iterations not executed
+    ray_walk<LOD_MODE, true, BELOW, STRIDE == 512>(r, active, nodes, stk, depth, coef, bias);
 #endif
 }
 
@@ -340,8 +341,134 @@ __device__ __forceinline__ void ray_run_total(Ray& r, bool active, const uint2* 
     ray_run<STRIDE, LOD_MODE>(r, active, nodes, stk, depth, coef, bias);
     book_walk_lanes(ctr, r.complexity);
 #else
-    static_assert(STRIDE == 256, "vrc_walk.h addresses LDS stack rows of 256 lanes");
-    const uint32_t wave_steps = ray_walk<LOD_MODE, false>(r, active, nodes, stk, depth, coef, bias);
+    static_assert(STRIDE == 256 || STRIDE == 512, "vrc_walk.h addresses LDS stack rows of 256 lanes, 1 or 2 KiB apart");
+    const uint32_t wave_steps = ray_walk<LOD_MODE, false, false, STRIDE == 512>(r, active, nodes, stk, depth, coef, bias);
+    book_walk(ctr, wave_steps);
+#endif
+}
+
+// ---- secondary rays that start below the root --------------------------------------------------------------------------
+// A ray that starts next to the hit of the ray before it (raycaster.hpp:139,153 the shadow ray; :171-176 the GI ray; :195-198
+// the GI shadow ray) begins, in the reference, with pure descends from the root to the cell that holds its origin: the child
+// is present and no leaf (the previous walk went through the same nodes), t_min = 0 lies before every exit, and the child
+// chosen at :66-68 / :107-109 is the one around the origin.  Those iterations leave exactly the state of a pop (:133-143) to
+// their last scale with pos = the origin, so the walk may start there: parent from the stack the previous walk left (its
+// rows above the hit are the path from the root; ray_walk stores the hit's parent in the row of the hit's scale), complexity
+// 22 - scale for the iterations not executed.  This holds when every comparison of the skipped iterations is decided with a
+// margin.  start_scale_next_to returns the smallest scale s0 that satisfies
+//   - origin and hit position agree in all bits above s0: both in [1, 2) and in the same cells down to the parent of scale s0,
+//   - s0 >= the scale of the hit (the deeper rows of the stack are not on the hit's path),
+//   - no multiple of 2^s0 ulps within 8 ulps of an origin coordinate: the comparisons test the centre planes of the cells
+//     above (c - o) * t_coef-wise, their rounding error is below 4.5 ulps of the coordinate,
+// or a value >= 22 when there is none (the ray then starts at the root).  The caller promises |d| = 1 and an LOD coefficient
+// <= 0.5 with bias 0: then the LOD test (:82) cannot fire in a cell that holds the origin (tc_max <= sqrt(3) * scale_f).
+// oracle/vrc_walk_model.c restates this on the CPU and tests/test_walk_model.py holds it to the oracle ray by ray.
+__device__ __forceinline__ uint32_t start_scale_next_to(float ox, float oy, float oz, float hx, float hy, float hz, uint32_t hit_scale)
+{
+    const uint32_t a = f2u(ox), b = f2u(oy), c = f2u(oz);
+    const uint32_t db = (a ^ f2u(hx)) | (b ^ f2u(hy)) | (c ^ f2u(hz));
+    const uint32_t mb = ((a - 8u) ^ (a + 8u)) | ((b - 8u) ^ (b + 8u)) | ((c - 8u) ^ (c + 8u));
+    const uint32_t bits = db | (mb + mb);
+    const int s = 31 - __clz((int)bits);                  // -1 for no bit at all
+    return (uint32_t)max(s, (int)hit_scale);
+}
+
+// The rows of one lane's stack column copied to another column: a walk that starts below the root on the copy leaves the
+// original, the path to the previous hit, to the next ray that starts from the same hit.  The two stacks' rows are
+// interleaved (STRIDE = 2 x 256 entries from one row to the next, dst = src + 256), so every address is the lane's base plus
+// a constant: LDS reads and writes with immediate offsets, no address arithmetic.
+template <int STRIDE>
+__device__ __forceinline__ void copy_stack(stack_t* dst, const stack_t* src, int depth)
+{
+    // three rows per LDS round trip (the reads of a group are issued together), then the one or two that are left; plain
+    // counted loops: unrolled with `i < depth` tests the compiler keeps a mask per test in SGPRs, which the kernels do not have
+#pragma unroll 1
+    for (int g = depth / 3; g > 0; --g) {
+        const stack_t a = src[0], b = src[STRIDE], c = src[2 * STRIDE];
+        dst[0] = a; dst[STRIDE] = b; dst[2 * STRIDE] = c;
+        src += 3 * STRIDE; dst += 3 * STRIDE;
+    }
+#pragma unroll 1
+    for (int g = depth % 3; g > 0; --g) {
+        dst[0] = src[0];
+        src += STRIDE; dst += STRIDE;
+    }
+}
+
+// The same idea for camera rays (main.cpp:149: every ray of a frame starts at, or with a lens within the aperture of, the
+// camera position): the path from the root to the cell around the camera, followed once per workgroup by position --
+// at every scale the child around the point (child_shift = the inverted position bits, whatever the ray's direction: the
+// mirrored frame inverts them once more) must exist and be no leaf, and the point must keep the margin of
+// start_scale_next_to from the planes of the next scale.  path[scale - depth_off] = parent at that scale, for the scales from
+// the returned one up to 22; a camera ray then starts like a ray next to a hit at the camera position with that scale.
+__device__ __forceinline__ uint32_t camera_path(const uint2* __restrict__ nodes, int depth, float cx, float cy, float cz, stack_t* path)
+{
+    const uint32_t a = f2u(cx), b = f2u(cy), c = f2u(cz);
+    const uint32_t mb = ((a - 8u) ^ (a + 8u)) | ((b - 8u) ^ (b + 8u)) | ((c - 8u) ^ (c + 8u));
+    // all three in [1, 2): sign 0, exponent 127 (the margin test covers the ends of the interval)
+    const bool inside = ((a >> 23) == 127u) && ((b >> 23) == 127u) && ((c >> 23) == 127u);
+    const int depth_off = SVO_MAX - depth;
+    // (copy_camera_path moves the rows in groups of three from the top: no deeper than the groups that fit the column)
+    const int lowest = max(max(31 - __clz((int)(mb + mb)), depth_off), SVO_MAX - 3 * (depth / 3));
+    int s = SVO_MAX - 1;
+    uint32_t parent = 0u;
+    if (inside) {
+        while (s > lowest) {
+            const uint2 nd = nodes[parent];
+            const uint32_t cs = 7u ^ (((a >> s) & 1u) | (((b >> s) & 1u) << 1) | (((c >> s) & 1u) << 2));
+            const uint32_t masks = nd.x >> cs;
+            if ((masks & 0x10100u) != 0x100u) break;      // no child (the walk advances here) or a leaf (it ends here)
+            path[s - depth_off] = parent;
+            parent += nd.y + cs;
+            --s;
+        }
+    }
+    path[s - depth_off] = parent;
+    return (uint32_t)s;
+}
+
+// the rows of a camera path from its scale up, into a lane's stack column (before every camera ray: walks overwrite them);
+// in groups of three from the top row -- what a group carries below the path's scale is never read
+template <int STRIDE>
+__device__ __forceinline__ void copy_camera_path(stack_t* dst, const stack_t* path, int depth, uint32_t cam_scale)
+{
+    dst += (depth - 3) * STRIDE; path += depth - 3;
+#pragma unroll 1
+    for (int g = cam_scale < 22u ? (SVO_MAX - (int)cam_scale + 2) / 3 : 0; g > 0; --g) {     // a path that ends at the root: nothing to copy
+        const stack_t a = path[0], b = path[1], c = path[2];
+        dst[0] = a; dst[STRIDE] = b; dst[2 * STRIDE] = c;
+        dst -= 3 * STRIDE; path -= 3;
+    }
+}
+
+// Turns the state ray_setup left (start at the root) into a start at scale s0 < 22 next to the previous hit: the position
+// is the ray's origin in the mirrored frame of the walk (:49-52; 3 - x is exact for x in [1, 2)); ray_walk<.., BELOW> derives
+// the rest (parent, scale_f, cell, child bits) the way a pop does.
+__device__ __forceinline__ void ray_start_below(Ray& r, uint32_t s0, float ox, float oy, float oz)
+{
+#if !(defined(VRC_WALK_CPP) || defined(VRC_PROBE) || defined(VRC_NO_START_BELOW))
+    if (s0 < 22u) {
+        r.px = (r.mirror & 1u) ? ox : 3.0f - ox;
+        r.py = (r.mirror & 2u) ? oy : 3.0f - oy;
+        r.pz = (r.mirror & 4u) ? oz : 3.0f - oz;
+        r.scale = (int)s0;
+    }
+#endif
+}
+
+// ray_run_total for a ray that may start below the root (ray_start_below)
+template <int STRIDE, int LOD_MODE>
+__device__ __forceinline__ void ray_run_total_below(Ray& r, bool active, const uint2* __restrict__ nodes, stack_t* stk,
+                                                    int depth, float coef, float bias, unsigned long long* ctr)
+{
+#if defined(VRC_WALK_CPP) || defined(VRC_PROBE) || defined(VRC_NO_START_BELOW)
+    ray_run_total<STRIDE, LOD_MODE>(r, active, nodes, stk, depth, coef, bias, ctr);     // from the root: the same walk
+#else
+    static_assert(STRIDE == 256 || STRIDE == 512, "vrc_walk.h addresses LDS stack rows of 256 lanes, 1 or 2 KiB apart");
+    const uint32_t not_executed = (uint32_t)(SVO_MAX - 1 - r.scale);
+    if (active && not_executed)                           // :73 for the iterations this lane does not execute
+        __hip_atomic_fetch_add(ctr + 0, (unsigned long long)not_executed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    const uint32_t wave_steps = ray_walk<LOD_MODE, false, true, STRIDE == 512>(r, active, nodes, stk, depth, coef, bias);
     book_walk(ctr, wave_steps);
 #endif
 }

@@ -826,6 +826,9 @@ k_render_tile(const FrameArgs a)
 // fastest: what the refill machinery saves in idle lanes it loses in transition
 // code executed at partial utilisation and in occupancy.
 
+// entries from one row of a stack to the next: the sync kernels keep two stacks with interleaved rows (render_sync_body)
+#define VRC_SYNC_ROW (2 * VRC_RENDER_BLOCK)
+
 #ifndef VRC_SYNC_MIN_WAVES
 #define VRC_SYNC_MIN_WAVES 6
 #endif
@@ -844,8 +847,11 @@ __device__ __forceinline__ uint32_t probe_wave_max(uint32_t v)
 // raycaster.hpp:169-207 getGlobalIllumination for one pixel-sample (+ the nested second bounce of the extension): GI
 // ray from the point (bp, bn), cast with LOD coefficient 0.5; if it hits, a shadow ray from the GI hit towards the
 // light.  Called by all lanes of a wave whose pixel-sample has a primary hit (`in exec`); the two walks are wave-wide.
+// `stk_hit` holds the path to the point's hit (the stack its walk left), `stk` is the stack the chain's walks use: the GI ray
+// starts below the root on a copy of that path, the GI shadow ray on what the GI walk left (vrc_device.h, ray_start_below).
 template <bool ONE_BOUNCE>   // true: gi_bounces == 1 is known (the reference's semantics), the chain is straight-line code
-__device__ __forceinline__ float gi_chain(const uint2* __restrict__ nodes, stack_t* stk, const uint2 root, const int depth,
+__device__ __forceinline__ float gi_chain(const uint2* __restrict__ nodes, stack_t* stk, const stack_t* stk_hit, const uint32_t base_scale,
+                                          const uint2 root, const int depth,
                                           const float n_normalizer, const float lx, const float ly, const float lz,
                                           const uint32_t gi_bounces_rt, const uint32_t seed, const uint32_t fr, const uint32_t pix,
                                           float base_px, float base_py, float base_pz, float base_nx, float base_ny, float base_nz,
@@ -876,7 +882,11 @@ __device__ __forceinline__ float gi_chain(const uint2* __restrict__ nodes, stack
         const float dot_gi = dot3(dx, dy, dz, base_nx, base_ny, base_nz);   // :193
         if (level == 0u) dgi[0] = dot_gi; else dgi[1] = dot_gi;
         active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
-        ray_run_total<VRC_RENDER_BLOCK, 1>(r, active, nodes, stk, depth, 0.5f, 0.0f, ctr);   // :194
+        if (level == 0u) {     // (a deeper level starts at the root: the GI shadow walk has used the stack since its hit)
+            copy_stack<VRC_SYNC_ROW>(stk, stk_hit, depth);
+            ray_start_below(r, start_scale_next_to(ox, oy, oz, base_px, base_py, base_pz, base_scale), ox, oy, oz);
+        }
+        ray_run_total_below<VRC_SYNC_ROW, 1>(r, active, nodes, stk, depth, 0.5f, 0.0f, ctr);   // :194
         Hit g;
         ray_finish(r, depth, ox, oy, oz, dx, dy, dz, g);
         chain = false;
@@ -889,7 +899,8 @@ __device__ __forceinline__ float gi_chain(const uint2* __restrict__ nodes, stack
             const float dotl = dot3(g.nx, g.ny, g.nz, dx, dy, dz);         // :200
             const float contrib = 1000000.0f * smin(0.5f, smax(0.0f, dotl) * dot_gi);   // :201
             active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
-            ray_run_total<VRC_RENDER_BLOCK, 1>(r, active, nodes, stk, depth, 0.5f, 0.0f, ctr);   // :198
+            ray_start_below(r, start_scale_next_to(ox, oy, oz, g.px, g.py, g.pz, (g.hit >> 16) & 0xffu), ox, oy, oz);
+            ray_run_total_below<VRC_SYNC_ROW, 1>(r, active, nodes, stk, depth, 0.5f, 0.0f, ctr);   // :198
             if (!r.kind) { if (level == 0u) acc[0] += contrib; else acc[1] += contrib; }
             if (level + 1u < gi_bounces) {
                 base_px = g.px; base_py = g.py; base_pz = g.pz;
@@ -909,7 +920,8 @@ __device__ __forceinline__ float gi_chain(const uint2* __restrict__ nodes, stack
 // rejects gi_bounces > 2, launch_render sends gi_bounces <= 1 to the one-bounce kernels).  Same operations in the same
 // order as gi_chain<false> with gi_bounces = 2 -- level 0 from the primary hit with draws 2, 3, level 1 from the GI hit with
 // draws 4, 5, gi = max(0, acc0 + dot_gi0 * max(0, acc1)) -- without the loop-carried level / draw / base state.
-__device__ __forceinline__ float gi_two_levels(const uint2* __restrict__ nodes, stack_t* stk, const uint2 root, const int depth,
+__device__ __forceinline__ float gi_two_levels(const uint2* __restrict__ nodes, stack_t* stk, const stack_t* stk_hit, const uint32_t base_scale,
+                                               const uint2 root, const int depth,
                                                const float n_normalizer, const float lx, const float ly, const float lz,
                                                const uint32_t seed, const uint32_t fr, const uint32_t pix,
                                                const float b0px, const float b0py, const float b0pz,
@@ -935,7 +947,9 @@ __device__ __forceinline__ float gi_two_levels(const uint2* __restrict__ nodes, 
         normalize3(dx, dy, dz);
         dgi0 = dot3(dx, dy, dz, b0nx, b0ny, b0nz);                        // :193
         active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
-        ray_run_total<VRC_RENDER_BLOCK, 1>(r, active, nodes, stk, depth, 0.5f, 0.0f, ctr);   // :194
+        copy_stack<VRC_SYNC_ROW>(stk, stk_hit, depth);
+        ray_start_below(r, start_scale_next_to(ox, oy, oz, b0px, b0py, b0pz, base_scale), ox, oy, oz);
+        ray_run_total_below<VRC_SYNC_ROW, 1>(r, active, nodes, stk, depth, 0.5f, 0.0f, ctr);   // :194
     }
     Hit g;
     ray_finish(r, depth, ox, oy, oz, dx, dy, dz, g);
@@ -948,7 +962,8 @@ __device__ __forceinline__ float gi_two_levels(const uint2* __restrict__ nodes, 
         const float dotl = dot3(g.nx, g.ny, g.nz, dx, dy, dz);             // :200
         const float contrib = 1000000.0f * smin(0.5f, smax(0.0f, dotl) * dgi0);   // :201
         active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
-        ray_run_total<VRC_RENDER_BLOCK, 1>(r, active, nodes, stk, depth, 0.5f, 0.0f, ctr);   // :198
+        ray_start_below(r, start_scale_next_to(ox, oy, oz, g.px, g.py, g.pz, (g.hit >> 16) & 0xffu), ox, oy, oz);
+        ray_run_total_below<VRC_SYNC_ROW, 1>(r, active, nodes, stk, depth, 0.5f, 0.0f, ctr);   // :198
         if (!r.kind) acc0 += contrib;
         // ---- level 1: the same from the GI hit
         const float b1nx = g.nx, b1ny = g.ny, b1nz = g.nz;
@@ -967,7 +982,7 @@ __device__ __forceinline__ float gi_two_levels(const uint2* __restrict__ nodes, 
         normalize3(dx, dy, dz);
         const float dgi1 = dot3(dx, dy, dz, b1nx, b1ny, b1nz);
         active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
-        ray_run_total<VRC_RENDER_BLOCK, 1>(r, active, nodes, stk, depth, 0.5f, 0.0f, ctr);
+        ray_run_total<VRC_SYNC_ROW, 1>(r, active, nodes, stk, depth, 0.5f, 0.0f, ctr);
         Hit g1;
         ray_finish(r, depth, ox, oy, oz, dx, dy, dz, g1);
         if (g1.hit) {
@@ -979,7 +994,8 @@ __device__ __forceinline__ float gi_two_levels(const uint2* __restrict__ nodes, 
             const float dotl1 = dot3(g1.nx, g1.ny, g1.nz, dx, dy, dz);
             const float contrib1 = 1000000.0f * smin(0.5f, smax(0.0f, dotl1) * dgi1);
             active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
-            ray_run_total<VRC_RENDER_BLOCK, 1>(r, active, nodes, stk, depth, 0.5f, 0.0f, ctr);
+            ray_start_below(r, start_scale_next_to(ox, oy, oz, g1.px, g1.py, g1.pz, (g1.hit >> 16) & 0xffu), ox, oy, oz);
+            ray_run_total_below<VRC_SYNC_ROW, 1>(r, active, nodes, stk, depth, 0.5f, 0.0f, ctr);
             if (!r.kind) acc1 += contrib1;
         }
         acc0 += dgi0 * smax(0.0f, acc1 / 1.0f);                            // :206, innermost level first
@@ -1020,9 +1036,11 @@ __device__ __forceinline__ uint32_t albedo_of(const uint8_t* tex, const Hit& h)
 template <bool PINHOLE, bool ONE_BOUNCE, bool FUSED>
 __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
 {
-    extern __shared__ stack_t lds_dyn[];   // [depth][256] stack | 1536 B textures | 4 waves x 4 counters
-    stack_t* stk = lds_dyn + threadIdx.x;
-    uint8_t* tex = reinterpret_cast<uint8_t*>(lds_dyn + a.depth * VRC_RENDER_BLOCK);
+    // [depth][2][256] two stacks, their rows interleaved | 1536 B textures | 4 waves x 4 counters | camera path (16 entries)
+    extern __shared__ stack_t lds_dyn[];
+    stack_t* stk = lds_dyn + threadIdx.x;                              // the path to the primary hit, kept until the next primary walk
+    stack_t* stk2 = stk + VRC_RENDER_BLOCK;                            // secondary rays: a copy of that path, then their own
+    uint8_t* tex = reinterpret_cast<uint8_t*>(lds_dyn + 2u * a.depth * VRC_RENDER_BLOCK);
     const uint32_t lane = threadIdx.x & 63u;
     for (uint32_t i = threadIdx.x; i < 1536u / 4u; i += VRC_RENDER_BLOCK)
         reinterpret_cast<uint32_t*>(tex)[i] = reinterpret_cast<const uint32_t*>(a.tex)[i];
@@ -1030,11 +1048,19 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
     // no-return LDS adds, so that no per-lane counter is live across the walks (the kernel is at its register budget)
     unsigned long long* const ctr = reinterpret_cast<unsigned long long*>(tex + 1536) + 4u * (threadIdx.x >> 6);
     if (lane < 4u) ctr[lane] = 0ull;
-    __syncthreads();
-
     const uint2* __restrict__ nodes = a.nodes;
-    const uint2 root = nodes[0];
     const int depth = (int)a.depth;
+    // the path from the root to the camera's cell (vrc_device.h, camera_path): camera rays start at its end
+    stack_t* const cam_path = reinterpret_cast<stack_t*>(tex + 1536 + 128);
+    if (threadIdx.x == 0u) {
+        const float isz = 1.0f / (float)(1u << a.depth);
+        cam_path[15] = camera_path(nodes, depth, (a.cam.position[0] + 0.0f) * isz + 1.0f, (a.cam.position[1] + 0.0f) * isz + 1.0f,
+                                   (a.cam.position[2] + 0.0f) * isz + 1.0f, cam_path);
+    }
+    __syncthreads();
+    const uint32_t cam_scale = __builtin_amdgcn_readfirstlane(cam_path[15]);
+
+    const uint2 root = nodes[0];
     const uint32_t W = a.width, H = a.height;
     const float inv_size = 1.0f / (float)(1u << a.depth);                 // main.cpp:82
     const float n_normalizer = inv_size * 0.0078125f * 2.0f;              // raycaster.hpp:171-172
@@ -1143,7 +1169,7 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
             const bool reuse = ka->reuse_invariant != 0u;
             const uint32_t n_walks = reuse ? 1u : n_samples, n_shadow_walks = reuse ? 1u : n_samples * shadow_samples;
             bool hit = false;
-            uint32_t albedo = 0u;
+            uint32_t albedo = 0u, hit_scale = 0u;
             float light_intensity = 0.0f;
             float hpx = 0.0f, hpy = 0.0f, hpz = 0.0f, hnx = 0.0f, hny = 0.0f, hnz = 0.0f;
             if (valid) {
@@ -1164,14 +1190,16 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
                 float oz = (a.cam.position[2] + 0.0f) * inv_size + 1.0f;
                 Ray r0, r;
                 bool active = ray_setup(r0, root, ox, oy, oz, dx, dy, dz);
+                ray_start_below(r0, cam_scale, ox, oy, oz);                         // every camera ray starts at the camera
                 r = r0;
                 for (uint32_t k = 0; k < n_walks; ++k) {                            // raycaster.hpp:131, once per sample
                     r = r0;
+                    copy_camera_path<VRC_SYNC_ROW>(stk, cam_path, depth, cam_scale);
                     if (a.prim) {                                                   // the capture records the ray's own complexity
-                        ray_run<VRC_RENDER_BLOCK, 0>(r, active, nodes, stk, depth, 0.0f, 0.0f);
+                        ray_run<VRC_SYNC_ROW, 0, true>(r, active, nodes, stk, depth, 0.0f, 0.0f);
                         book_walk_lanes(ctr, r.complexity);
                     } else {
-                        ray_run_total<VRC_RENDER_BLOCK, 0>(r, active, nodes, stk, depth, 0.0f, 0.0f, ctr);
+                        ray_run_total_below<VRC_SYNC_ROW, 0>(r, active, nodes, stk, depth, 0.0f, 0.0f, ctr);
                     }
                 }
                 Hit h;
@@ -1196,9 +1224,12 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
                     normalize3(dx, dy, dz);
                     const float lit = smax(0.0f, dot3(dx, dy, dz, h.nx, h.ny, h.nz));           // :156
                     active = ray_setup(r0, root, ox, oy, oz, dx, dy, dz);
+                    hit_scale = (h.hit >> 16) & 0xffu;
+                    ray_start_below(r0, start_scale_next_to(ox, oy, oz, h.px, h.py, h.pz, hit_scale), ox, oy, oz);
                     for (uint32_t k = n_shadow_walks; k--;) {
                         r = r0;
-                        ray_run_total<VRC_RENDER_BLOCK, 0>(r, active, nodes, stk, depth, 0.0f, 0.0f, ctr);
+                        copy_stack<VRC_SYNC_ROW>(stk2, stk, depth);
+                        ray_run_total_below<VRC_SYNC_ROW, 0>(r, active, nodes, stk2, depth, 0.0f, 0.0f, ctr);
                     }
                     if (!r.kind) light_intensity = lit;                                      // :155-157
                 }
@@ -1211,10 +1242,10 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
                         float gi_intensity = 0.0f;
                         if (a.p.use_gi) {
                             if constexpr (ONE_BOUNCE)
-                                gi_intensity = gi_chain<ONE_BOUNCE>(nodes, stk, root, depth, n_normalizer, lx, ly, lz, gi_bounces, a.p.seed,
+                                gi_intensity = gi_chain<ONE_BOUNCE>(nodes, stk2, stk, hit_scale, root, depth, n_normalizer, lx, ly, lz, gi_bounces, a.p.seed,
                                                     a.p.frame_index + sample, pix, hpx, hpy, hpz, hnx, hny, hnz, ctr);
                             else
-                                gi_intensity = gi_two_levels(nodes, stk, root, depth, n_normalizer, lx, ly, lz, a.p.seed,
+                                gi_intensity = gi_two_levels(nodes, stk2, stk, hit_scale, root, depth, n_normalizer, lx, ly, lz, a.p.seed,
                                                     a.p.frame_index + sample, pix, hpx, hpy, hpz, hnx, hny, hnz, ctr);
                         }
                         color = color_mult(albedo, smin(1.0f, smax(0.0f, light_intensity + gi_intensity)));   // :163
@@ -1265,11 +1296,16 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
                     float oz = (a.cam.position[2] + wz) * inv_size + 1.0f;
                     Ray r;
                     bool active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
+                    // the lens point is next to the camera position: it starts where their paths from the root part
+                    copy_camera_path<VRC_SYNC_ROW>(stk, cam_path, depth, cam_scale);
+                    ray_start_below(r, start_scale_next_to(ox, oy, oz, (a.cam.position[0] + 0.0f) * inv_size + 1.0f,
+                                                           (a.cam.position[1] + 0.0f) * inv_size + 1.0f,
+                                                           (a.cam.position[2] + 0.0f) * inv_size + 1.0f, cam_scale), ox, oy, oz);
                     if (a.prim) {                                                   // the capture records the ray's own complexity
-                        ray_run<VRC_RENDER_BLOCK, 0>(r, active, nodes, stk, depth, 0.0f, 0.0f);
+                        ray_run<VRC_SYNC_ROW, 0, true>(r, active, nodes, stk, depth, 0.0f, 0.0f);
                         book_walk_lanes(ctr, r.complexity);
                     } else {
-                        ray_run_total<VRC_RENDER_BLOCK, 0>(r, active, nodes, stk, depth, 0.0f, 0.0f, ctr);
+                        ray_run_total_below<VRC_SYNC_ROW, 0>(r, active, nodes, stk, depth, 0.0f, 0.0f, ctr);
                     }
                     VRC_PROBE_WALK(r, 0)
                     Hit h;
@@ -1295,7 +1331,9 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
                             normalize3(dx, dy, dz);
                             const float lit = smax(0.0f, dot3(dx, dy, dz, h.nx, h.ny, h.nz));       // :156
                             active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
-                            ray_run_total<VRC_RENDER_BLOCK, 0>(r, active, nodes, stk, depth, 0.0f, 0.0f, ctr);
+                            copy_stack<VRC_SYNC_ROW>(stk2, stk, depth);
+                            ray_start_below(r, start_scale_next_to(ox, oy, oz, h.px, h.py, h.pz, (h.hit >> 16) & 0xffu), ox, oy, oz);
+                            ray_run_total_below<VRC_SYNC_ROW, 0>(r, active, nodes, stk2, depth, 0.0f, 0.0f, ctr);
                             VRC_PROBE_WALK(r, 1)
                             if (!r.kind) light_intensity = lit;                                  // :155-157
                         }
@@ -1303,10 +1341,10 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
                         float gi_intensity = 0.0f;
                         if (a.p.use_gi) {
                             if constexpr (ONE_BOUNCE)
-                                gi_intensity = gi_chain<ONE_BOUNCE>(nodes, stk, root, depth, n_normalizer, lx, ly, lz, gi_bounces, a.p.seed, fr, pix,
+                                gi_intensity = gi_chain<ONE_BOUNCE>(nodes, stk2, stk, (h.hit >> 16) & 0xffu, root, depth, n_normalizer, lx, ly, lz, gi_bounces, a.p.seed, fr, pix,
                                                     h.px, h.py, h.pz, h.nx, h.ny, h.nz, ctr);
                             else
-                                gi_intensity = gi_two_levels(nodes, stk, root, depth, n_normalizer, lx, ly, lz, a.p.seed, fr, pix,
+                                gi_intensity = gi_two_levels(nodes, stk2, stk, (h.hit >> 16) & 0xffu, root, depth, n_normalizer, lx, ly, lz, a.p.seed, fr, pix,
                                                     h.px, h.py, h.pz, h.nx, h.ny, h.nz, ctr);
                         }
                         color = color_mult(albedo, smin(1.0f, smax(0.0f, light_intensity + gi_intensity)));   // :163
@@ -1654,7 +1692,7 @@ hipError_t launch_render(const FrameArgs& a, uint32_t grid_blocks, int kernel, h
         const size_t lds = (size_t)a.depth * VRC_RENDER_BLOCK * sizeof(stack_t) + 4 * TILE_WAVE_LDS + 1536;
         hipLaunchKernelGGL(k_render_tile, dim3(grid_blocks), dim3(VRC_RENDER_BLOCK), lds, st, a);
     } else {
-        const size_t lds = (size_t)a.depth * VRC_RENDER_BLOCK * sizeof(stack_t) + 1536 + 128;   // + the waves' counters
+        const size_t lds = 2 * (size_t)a.depth * VRC_RENDER_BLOCK * sizeof(stack_t) + 1536 + 128 + 64;   // two stacks, tables, the waves' counters, camera path
         const bool pinhole = camera_is_pinhole(a.cam);
         const bool one = a.p.gi_bounces <= 1u, fused = a.fused_resolve != 0u;
         const uint32_t waves = a.waves;

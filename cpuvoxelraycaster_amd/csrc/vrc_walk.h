@@ -84,19 +84,31 @@ __device__ __forceinline__ walk_rsrc_t walk_node_rsrc(const uint2* __restrict__ 
 
 #ifdef VRC_WALK_GLOBAL_LOAD   /* A/B: the byte offset computed by the VALU */
 #define VRC_WALK_LOAD_NODE "v_lshlrev_b32_e32 %[m], 3, %[pid]\n global_load_dwordx2 v[46:47], %[m], %[nodes]\n"
+#define VRC_WALK_NODES_OPERAND [nodes] "s"(nodes),
 #else
 #define VRC_WALK_LOAD_NODE "buffer_load_dwordx2 v[46:47], %[pid], %[rsrc], 0 idxen\n"
+#define VRC_WALK_NODES_OPERAND [rsrc] "s"(rsrc),
 #endif
 
+// Start below the root (ray_walk's BELOW): the lanes whose start scale (in %[t]) is below 22 enter through the second half of the pop block with their start
+// scale in %[t] and the (mirrored) ray origin in px, py, pz -- stack row -> parent, scale_f, pos = the origin's bits above the
+// scale, child bits, node load: exactly the state a pop to that scale leaves (:133-143).  The other lanes start at the root.
+#define VRC_WALK_START_ROOT ""
+#define VRC_WALK_START_BELOW                                                                    \
+    "v_cmpx_gt_u32_e32 vcc, 22, %[t]\n"                                                         \
+    "s_cbranch_execnz Lwalk_start%=\n"                                                          \
+    "s_mov_b64 exec, %[srun]\n"
+
 // v46:47 node
-#define VRC_WALK_ASM(SPANPART, COUNTPART)                                                       \
+#define VRC_WALK_ASM(SPANPART, COUNTPART, STARTPART, ROWSH, ROWDOWN)                                           \
     "s_mov_b64 %[sentry], exec\n"                                                               \
-    "s_and_b64 exec, exec, %[sact]\n"           /* the lanes with a ray to walk */              \
+    "s_and_b64 exec, exec, %[sx]\n"             /* the lanes with a ray to walk (%[sx] arrives holding them) */ \
     "s_mov_b64 %[sleaf], 0\n"                                                                   \
     "s_mov_b64 %[slod], 0\n"                                                                    \
     "s_mov_b32 %[siter], 0xfffeffff\n"          /* carries out at the 65537th loop top: MAX_ITERATIONS */ \
     "s_mov_b64 %[srun], exec\n"                                                                 \
     "s_cbranch_execz Lwalk_done%=\n"                                                            \
+    STARTPART                                                                                   \
     "Lwalk_loop%=:\n"                                                                           \
     "s_add_u32 %[siter], %[siter], 1\n"                                                         \
     "s_cbranch_scc1 Lwalk_done%=\n"             /* safety net */                                \
@@ -140,7 +152,7 @@ __device__ __forceinline__ walk_rsrc_t walk_node_rsrc(const uint2* __restrict__ 
     "v_sub_f32_e32 %[m], %[tmin], %[m]\n"                                                       \
     "v_sub_f32_e32 %[t], %[tmin], %[t]\n"                                                       \
     "v_sub_f32_e32 %[t2], %[tmin], %[t2]\n"                                                     \
-    "v_add_u32_e32 %[sp], 0xfffffc00, %[sp]\n"  /* :104 --scale: the next stack row down */     \
+    "v_add_u32_e32 %[sp], " ROWDOWN ", %[sp]\n"  /* :104 --scale: the next stack row down */    \
     "v_ashrrev_i32_e32 %[m], 31, %[m]\n"                                                        \
     "v_ashrrev_i32_e32 %[t], 31, %[t]\n"                                                        \
     "v_ashrrev_i32_e32 %[t2], 31, %[t2]\n"                                                      \
@@ -163,10 +175,10 @@ __device__ __forceinline__ walk_rsrc_t walk_node_rsrc(const uint2* __restrict__ 
     "v_mov_b32_e32 %[tmin], %[tc]\n"            /* :120 */                                      \
     "v_cndmask_b32_e64 %[normal], 0, 1, vcc\n"                                                  \
     "v_cndmask_b32_e64 %[kind], 0, %[sf], %[sx]\n"                                                \
-    "v_addc_co_u32_e64 %[normal], %[st], %[normal], %[normal], %[sy]\n"                         \
+    "v_addc_co_u32_e64 %[normal], %[sin], %[normal], %[normal], %[sy]\n"   /* (carry out: into the dead sin) */ \
     "v_cndmask_b32_e64 %[m], 0, %[sf], %[sy]\n"                                                \
     "v_cndmask_b32_e32 %[t2], 0, %[sf], vcc\n"                                                  \
-    "v_addc_co_u32_e64 %[normal], %[st], %[normal], %[normal], %[sx]\n"   /* :122 */            \
+    "v_addc_co_u32_e64 %[normal], %[sin], %[normal], %[normal], %[sx]\n"  /* :122 */            \
     "v_sub_f32_e32 %[px], %[px], %[kind]\n"                                                       \
     "v_sub_f32_e32 %[py], %[py], %[m]\n"                                                       \
     "v_sub_f32_e32 %[pz], %[pz], %[t2]\n"                                                       \
@@ -188,7 +200,8 @@ __device__ __forceinline__ walk_rsrc_t walk_node_rsrc(const uint2* __restrict__ 
     "s_andn2_b64 %[srun], %[srun], vcc\n"                                                       \
     "s_andn2_b64 exec, exec, vcc\n"                                                             \
     "s_cbranch_scc0 Lwalk_next%=\n"                                                             \
-    "v_lshl_add_u32 %[sp], %[t], 10, %[stkb]\n"                                                 \
+    "Lwalk_start%=:\n"                                                                          \
+    "v_lshl_add_u32 %[sp], %[t], " ROWSH ", %[stkb]\n"                                                 \
     "ds_read_b32 %[pid], %[sp]\n"               /* :134-136 */                                  \
     "v_lshl_add_u32 %[sf], %[t], 23, %[sfc]\n"  /* :133 2^(scale-23) */                         \
     "v_lshlrev_b32_e64 %[t2], %[t], -1\n"       /* (the steps in cs, m, t2 are dead by now) */  \
@@ -207,7 +220,7 @@ __device__ __forceinline__ walk_rsrc_t walk_node_rsrc(const uint2* __restrict__ 
     "s_cbranch_execnz Lwalk_loop%=\n"                                                           \
     "Lwalk_done%=:\n"                                                                           \
     "s_waitcnt vmcnt(0) lgkmcnt(0)\n"                                                           \
-    "s_and_b64 exec, %[sentry], %[sact]\n"                                                      \
+    "s_or_b64 exec, %[sleaf], %[slod]\n"                                                        \
     "ds_write_b32 %[sp], %[pid]\n"              /* the parent of the hit in the row of its scale: with the rows above it, \
                                                    the path from the root (a ray that starts next to the hit reads it) */ \
     "s_mov_b64 exec, %[sentry]\n"                                                               \
@@ -215,11 +228,16 @@ __device__ __forceinline__ walk_rsrc_t walk_node_rsrc(const uint2* __restrict__ 
     "v_cndmask_b32_e64 %[kind], %[kind], 2, %[slod]\n"
 
 // Runs the walk for the lanes with `active` set (the others keep their state: kind 0, complexity 0).
-// `stk` = this lane's column of the LDS stack, `depth` rows of 256 lanes (1 KiB apart).
+// `stk` = this lane's column of the LDS stack, `depth` rows of 256 lanes, 1 KiB apart, or 2 KiB (TWO_STACKS: the frame
+// kernels keep two stacks, their rows interleaved, so that one is the other plus a constant: copy_stack).
 // COUNT_LANE: r.complexity is maintained (per lane); otherwise it is left alone and the return value is the number of
 // loop iterations all the wave's lanes executed in this call together (the same value in every lane that made the call).
 // r.h is not maintained (see the push above); nothing reads it after a walk.
-template <int LOD_MODE, bool COUNT_LANE>
+// BELOW: lanes whose r.scale is below 22 (ray_start_below in vrc_device.h set it, and r.px, r.py, r.pz to the ray's origin)
+// start at that scale instead of at the root -- see start_scale_next_to for when that is the walk the reference does; the
+// iterations such a lane does not execute (22 - scale) are NOT in the return value, the caller books them (COUNT_LANE: the
+// caller presets r.complexity with them).
+template <int LOD_MODE, bool COUNT_LANE, bool BELOW = false, bool TWO_STACKS = false>
 __device__ __forceinline__ uint32_t ray_walk(Ray& r, bool active, const uint2* __restrict__ nodes, stack_t* stk,
                                              int depth, float coef, float bias)
 {
@@ -228,45 +246,53 @@ __device__ __forceinline__ uint32_t ray_walk(Ray& r, bool active, const uint2* _
     const unsigned long long sact = __ballot(active);
     // LDS byte address of slot 0 minus the rows of the scales that have no slot (slot = scale - depth_off)
     const uint32_t stkb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) stack_t*)stk
-                          - (uint32_t)(SVO_MAX - depth) * 1024u;
+                          - (uint32_t)(SVO_MAX - depth) * (TWO_STACKS ? 2048u : 1024u);
     const uint32_t sfc = 104u << 23;            // (scale - 23 + 127) << 23 = (scale << 23) + (104 << 23)
     const walk_rsrc_t rsrc = walk_node_rsrc(nodes);
-    uint64_t sentry, sleaf, slod, srun, sin_, sx, sy, st;   // sx / sy: the x / y step masks of the advance
-    uint32_t siter, m, t, t2, kind, ssteps = 0u, sb;
+    uint64_t sentry, sleaf, slod, srun, sin_, sy;
+    uint64_t sx = sact;                         // the lanes to walk on entry, then the x step mask of the advance (sy: the y mask)
+    uint32_t siter, m, t = (uint32_t)r.scale, t2, kind, ssteps = 0u, sb;
     float tc, cx, cy, cz;
     float px = r.px, py = r.py, pz = r.pz, t_min = r.t_min, sf = r.scale_f;
     uint32_t pid = r.parent_id, ndx = r.nd.x, ndy = r.nd.y;
-    uint32_t sp = stkb + ((uint32_t)r.scale << 10);          // the level, as the LDS address of its stack row
+    uint32_t sp = stkb + ((uint32_t)r.scale << (TWO_STACKS ? 11 : 10));   // the level, as the LDS address of its stack row
     uint32_t co = r.child_offset, normal = r.normal, cmpl = COUNT_LANE ? r.complexity : 0u;
-#define VRC_WALK_OPERANDS(COUNT_OPERANDS)                                                                         \
-        : [kind] "=&v"(kind), COUNT_OPERANDS, [sp] "+&v"(sp), [co] "+&v"(co), [normal] "+&v"(normal),                     \
+#define VRC_WALK_OPERANDS(...)                                                                                    \
+        : [kind] "=&v"(kind), __VA_ARGS__, [sp] "+&v"(sp), [co] "+&v"(co), [normal] "+&v"(normal),                     \
           [px] "+&v"(px), [py] "+&v"(py), [pz] "+&v"(pz), [tmin] "+&v"(t_min), [pid] "+&v"(pid),                          \
           [sf] "+&v"(sf), "+{v46}"(ndx), "+{v47}"(ndy),                                                                \
           [sentry] "=&s"(sentry), [sleaf] "=&s"(sleaf), [slod] "=&s"(slod), [srun] "=&s"(srun), [sin] "=&s"(sin_),    \
-          [sx] "=&s"(sx), [sy] "=&s"(sy), [st] "=&s"(st),                                                             \
-          [siter] "=&s"(siter), [m] "=&v"(m), [t] "=&v"(t), [t2] "=&v"(t2), [tc] "=&v"(tc),                           \
+          [sx] "+&s"(sx), [sy] "=&s"(sy),                                                                             \
+          [siter] "=&s"(siter), [m] "=&v"(m), [t] "+&v"(t), [t2] "=&v"(t2), [tc] "=&v"(tc),                           \
           [cx] "=&v"(cx), [cy] "=&v"(cy), [cz] "=&v"(cz)                                                              \
         : [tcx] "v"(r.tcx), [tcy] "v"(r.tcy), [tcz] "v"(r.tcz), [tox] "v"(r.tox), [toy] "v"(r.toy), [toz] "v"(r.toz), \
-          [mirror] "v"(r.mirror), [stkb] "v"(stkb), [rsrc] "s"(rsrc), [nodes] "s"(nodes), [sfc] "s"(sfc), [coef] "v"(coef), [bias] "v"(bias), [tmax] "v"(r.t_max), \
-          [sact] "s"(sact)                                                                                             \
+          [mirror] "v"(r.mirror), [stkb] "v"(stkb), VRC_WALK_NODES_OPERAND [sfc] "s"(sfc), [coef] "v"(coef), [bias] "v"(bias), [tmax] "v"(r.t_max) \
         : "vcc", "scc", "memory"
 #define VRC_WALK_OPS_LANE [cmpl] "+&v"(cmpl)
 #define VRC_WALK_OPS_WAVE [ssteps] "+&s"(ssteps), [sb] "=&s"(sb)
+#define VRC_WALK_RUN(SPAN, COUNT, OPS)                                                                              \
+    do {                                                                                                            \
+        if (BELOW && TWO_STACKS) asm volatile(VRC_WALK_ASM(SPAN, COUNT, VRC_WALK_START_BELOW, "11", "0xfffff800") VRC_WALK_OPERANDS(OPS)); \
+        else if (TWO_STACKS) asm volatile(VRC_WALK_ASM(SPAN, COUNT, VRC_WALK_START_ROOT, "11", "0xfffff800") VRC_WALK_OPERANDS(OPS)); \
+        else if (BELOW) asm volatile(VRC_WALK_ASM(SPAN, COUNT, VRC_WALK_START_BELOW, "10", "0xfffffc00") VRC_WALK_OPERANDS(OPS));      \
+        else asm volatile(VRC_WALK_ASM(SPAN, COUNT, VRC_WALK_START_ROOT, "10", "0xfffffc00") VRC_WALK_OPERANDS(OPS));                  \
+    } while (0)
     if (COUNT_LANE) {
-        if (LOD_MODE == 0) asm volatile(VRC_WALK_ASM(VRC_WALK_SPAN_NOLOD, VRC_WALK_COUNT_LANE) VRC_WALK_OPERANDS(VRC_WALK_OPS_LANE));
-        else if (LOD_MODE == 1) asm volatile(VRC_WALK_ASM(VRC_WALK_SPAN_LOD(VRC_WALK_BIAS_NONE), VRC_WALK_COUNT_LANE) VRC_WALK_OPERANDS(VRC_WALK_OPS_LANE));
-        else asm volatile(VRC_WALK_ASM(VRC_WALK_SPAN_LOD(VRC_WALK_BIAS_ADD), VRC_WALK_COUNT_LANE) VRC_WALK_OPERANDS(VRC_WALK_OPS_LANE));
+        if (LOD_MODE == 0) VRC_WALK_RUN(VRC_WALK_SPAN_NOLOD, VRC_WALK_COUNT_LANE, VRC_WALK_OPS_LANE);
+        else if (LOD_MODE == 1) VRC_WALK_RUN(VRC_WALK_SPAN_LOD(VRC_WALK_BIAS_NONE), VRC_WALK_COUNT_LANE, VRC_WALK_OPS_LANE);
+        else VRC_WALK_RUN(VRC_WALK_SPAN_LOD(VRC_WALK_BIAS_ADD), VRC_WALK_COUNT_LANE, VRC_WALK_OPS_LANE);
     } else {
-        if (LOD_MODE == 0) asm volatile(VRC_WALK_ASM(VRC_WALK_SPAN_NOLOD, VRC_WALK_COUNT_WAVE) VRC_WALK_OPERANDS(VRC_WALK_OPS_WAVE));
-        else if (LOD_MODE == 1) asm volatile(VRC_WALK_ASM(VRC_WALK_SPAN_LOD(VRC_WALK_BIAS_NONE), VRC_WALK_COUNT_WAVE) VRC_WALK_OPERANDS(VRC_WALK_OPS_WAVE));
-        else asm volatile(VRC_WALK_ASM(VRC_WALK_SPAN_LOD(VRC_WALK_BIAS_ADD), VRC_WALK_COUNT_WAVE) VRC_WALK_OPERANDS(VRC_WALK_OPS_WAVE));
+        if (LOD_MODE == 0) VRC_WALK_RUN(VRC_WALK_SPAN_NOLOD, VRC_WALK_COUNT_WAVE, VRC_WALK_OPS_WAVE);
+        else if (LOD_MODE == 1) VRC_WALK_RUN(VRC_WALK_SPAN_LOD(VRC_WALK_BIAS_NONE), VRC_WALK_COUNT_WAVE, VRC_WALK_OPS_WAVE);
+        else VRC_WALK_RUN(VRC_WALK_SPAN_LOD(VRC_WALK_BIAS_ADD), VRC_WALK_COUNT_WAVE, VRC_WALK_OPS_WAVE);
     }
+#undef VRC_WALK_RUN
 #undef VRC_WALK_OPS_LANE
 #undef VRC_WALK_OPS_WAVE
 #undef VRC_WALK_OPERANDS
     r.px = px; r.py = py; r.pz = pz; r.t_min = t_min; r.scale_f = sf;
     r.parent_id = pid; r.nd = make_uint2(ndx, ndy);
-    r.scale = (int)((sp - stkb) >> 10); r.child_offset = co; r.normal = normal;
+    r.scale = (int)((sp - stkb) >> (TWO_STACKS ? 11 : 10)); r.child_offset = co; r.normal = normal;
     if (COUNT_LANE) r.complexity = cmpl;
     r.kind = kind;                              // 0 for a lane without a ray, as ray_setup left it
     r.shift = co ^ r.mirror;                    // child_shift of the child that was hit (unused on a miss)
