@@ -688,6 +688,7 @@ typedef struct {
     uint32_t trace_n;
     uint8_t *ops;              /* analysis hook: this pixel's per-iteration op codes, ORC_TRACE_RAYS x ops_len bytes */
     uint32_t ops_len;
+    float *geo;                /* analysis hook: this pixel's rays as {origin[3], hit position[3], hit scale, hit kind}, ORC_TRACE_RAYS x 8 floats */
 } shade_ctx;
 
 static void ctx_cast(shade_ctx *c, v3 o, v3 d, float coef, float bias, orc_hit *out)
@@ -698,6 +699,12 @@ static void ctx_cast(shade_ctx *c, v3 o, v3 d, float coef, float bias, orc_hit *
     orc_optrace = 0;
     c->rays += 1;
     c->sum_complexity += out->complexity;
+    if (c->geo && c->trace_n < ORC_TRACE_RAYS) {
+        float *g = c->geo + (size_t)c->trace_n * 8;
+        g[0] = o.x; g[1] = o.y; g[2] = o.z;
+        g[3] = out->position[0]; g[4] = out->position[1]; g[5] = out->position[2];
+        g[6] = (float)((out->hit >> 16) & 0xffu); g[7] = (float)(out->hit & 0xffu);
+    }
     if (c->trace && c->trace_n < ORC_TRACE_RAYS)
         c->trace[c->trace_n++] = (uint16_t)(out->complexity < 65535u ? out->complexity : 65535u);
 }
@@ -749,6 +756,7 @@ static void texture_color(const shade_ctx *c, const orc_hit *pt, uint8_t out[3])
 /* analysis hook: per-pixel op traces of the frame being rendered (set by orc_render_frame_optrace) */
 static uint8_t *orc_frame_ops;
 static uint32_t orc_frame_ops_len;
+static float *orc_frame_geo;   /* ... and origin / hit position / hit scale of every ray (orc_render_frame_optrace_geo) */
 
 /* raycaster.hpp:169-207; `level` > 0 only for the gi_bounces >= 2 extension. */
 static float global_illumination(shade_ctx *c, const orc_hit *point, rng_t *rng, float inv_size,
@@ -849,6 +857,7 @@ static void render_pixel(shade_ctx *c, const orc_camera *cam, const orc_frame_pa
     c->trace_n = 0;
     c->ops = (trace && orc_frame_ops) ? orc_frame_ops + ((uint64_t)y * W + x) * ORC_TRACE_RAYS * orc_frame_ops_len : 0;
     c->ops_len = orc_frame_ops_len;
+    c->geo = (trace && orc_frame_geo) ? orc_frame_geo + ((uint64_t)y * W + x) * ORC_TRACE_RAYS * 8 : 0;
     const float inv_size = 1.0f / (float)(1u << c->depth);     /* main.cpp:82 */
     rng_t rng = { p->rng_mode, p->seed, p->frame_index, y * W + x, 0u };
     /* main.cpp:133,145-146 */
@@ -909,7 +918,7 @@ void orc_render_frame_trace(const orc_lnode *nodes, uint32_t depth,
         /* serial: the reference's own pixel order within its 4x4 tiles is
          * thread-racy; x-outer/y-inner (main.cpp:142-143) over the whole frame here */
         shade_ctx c = { nodes, depth, tex_top, tex_side,
-                        { p->light_position[0], p->light_position[1], p->light_position[2] }, 0, 0, 0, 0, 0, 0 };
+                        { p->light_position[0], p->light_position[1], p->light_position[2] }, 0, 0, 0, 0, 0, 0, 0 };
         for (uint32_t x = 0; x < W; x++)
             for (uint32_t y = 0; y < H; y++)
                 if (pixel_selected(p, x, y))
@@ -919,7 +928,7 @@ void orc_render_frame_trace(const orc_lnode *nodes, uint32_t depth,
 #pragma omp parallel for schedule(dynamic, 4) num_threads(threads) reduction(+ : rays, sumc)
         for (int32_t y = 0; y < (int32_t)H; y++) {
             shade_ctx c = { nodes, depth, tex_top, tex_side,
-                            { p->light_position[0], p->light_position[1], p->light_position[2] }, 0, 0, 0, 0, 0, 0 };
+                            { p->light_position[0], p->light_position[1], p->light_position[2] }, 0, 0, 0, 0, 0, 0, 0 };
             for (uint32_t x = 0; x < W; x++)
                 if (pixel_selected(p, x, (uint32_t)y))
                     render_pixel(&c, cam, p, x, (uint32_t)y, image, accum, prim, trace);
@@ -946,6 +955,18 @@ void orc_render_frame_optrace(const orc_lnode *nodes, uint32_t depth,
     free(image); free(accum);
 }
 
+/* ... plus, per pixel and ray, {origin[3], hit position[3], hit scale, hit kind} into geo[(pixel * ORC_TRACE_RAYS + ray) * 8]:
+ * what tests/tools/path_schedule.py needs to tell where the kernel starts each ray (below the root, next to the previous hit). */
+void orc_render_frame_optrace_geo(const orc_lnode *nodes, uint32_t depth,
+                                  const uint8_t tex_top[768], const uint8_t tex_side[768],
+                                  const orc_camera *cam, const orc_frame_params *p,
+                                  int threads, uint16_t *trace, uint8_t *ops, uint32_t ops_len, float *geo)
+{
+    orc_frame_geo = geo;
+    orc_render_frame_optrace(nodes, depth, tex_top, tex_side, cam, p, threads, trace, ops, ops_len);
+    orc_frame_geo = 0;
+}
+
 /* The same frame with the REFERENCE's own decomposition (main.cpp:90-92,139-152): 16 threads, thread t owns the
  * area (t % 4, t / 4) of (W/4) x (H/4) pixels and walks it x-outer / y-inner; pixels beyond 4*(W/4) x 4*(H/4) are
  * never rendered (as in the reference).  Static assignment, no work stealing: the frame takes as long as its
@@ -963,7 +984,7 @@ void orc_render_frame_areas16(const orc_lnode *nodes, uint32_t depth,
 #pragma omp for schedule(static, 1)
         for (int t = 0; t < 16; t++) {
             shade_ctx c = { nodes, depth, tex_top, tex_side,
-                            { p->light_position[0], p->light_position[1], p->light_position[2] }, 0, 0, 0, 0, 0, 0 };
+                            { p->light_position[0], p->light_position[1], p->light_position[2] }, 0, 0, 0, 0, 0, 0, 0 };
             const uint32_t x0 = ((uint32_t)t % 4u) * aw, y0 = ((uint32_t)t / 4u) * ah;
             for (uint32_t x = x0; x < x0 + aw; x++)
                 for (uint32_t y = y0; y < y0 + ah; y++)
@@ -987,7 +1008,7 @@ void orc_area_job(uint32_t id, uint32_t worker_count, void *user)
     const uint32_t aw = p->width / 4u, ah = p->height / 4u;
     if (id >= 16u) return;
     shade_ctx c = { f->nodes, f->depth, f->tex_top, f->tex_side,
-                    { p->light_position[0], p->light_position[1], p->light_position[2] }, 0, 0, 0, 0, 0, 0 };
+                    { p->light_position[0], p->light_position[1], p->light_position[2] }, 0, 0, 0, 0, 0, 0, 0 };
     const uint32_t x0 = (id % 4u) * aw, y0 = (id / 4u) * ah;
     for (uint32_t x = x0; x < x0 + aw; x++)
         for (uint32_t y = y0; y < y0 + ah; y++)

@@ -77,8 +77,10 @@ def test_issue_model_reads_the_walk_loop_and_is_current():
     import issue_model
     nolod, lod = issue_model.block_counts(0, False), issue_model.block_counts(1, False)
     valu = lambda b: sum(b.get(c, 0) for c in "ABSQP")
-    assert [valu(nolod[k]) for k in ("header", "descend", "advance", "pop")] == [14, 25, 16, 21]
+    assert [valu(nolod[k]) for k in ("header", "descend", "advance", "pop")] == [14, 24, 16, 21]
     assert valu(lod["header"]) == 16 and lod["header"]["Q"] == 6          # + the LOD product and its compare
+    assert valu(lod["descend"]) == 24                                     # no t_max update: the stack entry is the parent alone
+    assert valu(nolod["start"]) == 11 and nolod["start"]["lds"] == 1 and nolod["start"]["vmem"] == 1   # entry of a ray that starts below the root
     assert all(b.get("P", 0) == 0 for b in nolod.values())               # no packed / lane-access instruction in the loop
     assert nolod["descend"]["lds"] == 1 and nolod["pop"]["lds"] == 1 and nolod["descend"]["vmem"] == 1 and nolod["pop"]["vmem"] == 1
     lane = issue_model.block_counts(0, True)                             # per-lane complexity: one VALU more, two scalar fewer

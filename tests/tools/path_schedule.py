@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """Offline study (CPU, oracle only): instruction issue of the walk loop under different ways of scheduling its three
-divergent paths inside a wave, from the oracle's per-iteration op traces (orc_render_frame_optrace) of a strided band of
+divergent paths inside a wave, from the oracle's per-iteration op traces (orc_render_frame_optrace_geo) of a strided band of
 the C3 frame.  A wave issues a block at full cost whenever ANY of its lanes needs it; per round (vrc_walk.h):
-header 13 VALU (15 with the LOD test), descend 25, advance 15, pop 22.  ANALYSIS INFRASTRUCTURE: uses oracle/ only.
+header 13 VALU (15 with the LOD test), descend 25, advance 15, pop 22.  Every ray starts where the kernel starts it: below
+the root, at the scale vrc_device.h's start_scale_next_to / camera_path give for it (the iterations before that are not
+executed), computed here from the trace's ray origins and hit positions.  ANALYSIS INFRASTRUCTURE: uses oracle/ only.
 
     python tests/tools/path_schedule.py [--band 16]
 """
@@ -20,10 +22,51 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 H_, D_, A_, P_ = 13.0, 25.0, 15.0, 22.0
 
 
-def simulate(ops, length, policy, lod):
-    """ops: (64, L) uint8 op codes, length: (64,) iterations per lane (0 = no ray).  Returns issued VALU instructions."""
+def highbit(x):
+    """index of the highest set bit of uint32 values, -1 for 0"""
+    x = np.asarray(x, np.uint64)
+    out = np.full(x.shape, -1, np.int64)
+    for b in range(32):
+        out[(x >> np.uint64(b)) & np.uint64(1) == 1] = b
+    return out
+
+
+def start_scale_next_to(o, h, hit_scale):
+    """numpy restatement of vrc_device.h's start_scale_next_to; o, h: (..., 3) float32"""
+    a = np.ascontiguousarray(o, np.float32).view(np.uint32).astype(np.uint64)
+    b = np.ascontiguousarray(h, np.float32).view(np.uint32).astype(np.uint64)
+    m32 = np.uint64(0xffffffff)
+    db = np.bitwise_or.reduce(a ^ b, axis=-1)
+    mb = np.bitwise_or.reduce(((a - np.uint64(8)) & m32) ^ ((a + np.uint64(8)) & m32), axis=-1)
+    return np.maximum(highbit((db | (mb + mb)) & m32), np.asarray(hit_scale, np.int64))
+
+
+def camera_path_scale(nodes, depth, cam):
+    """numpy restatement of camera_path: the scale at which camera rays start (22 = at the root)"""
+    a = np.asarray(cam, np.float32).view(np.uint32).astype(np.uint64)
+    m32 = np.uint64(0xffffffff)
+    mb = int(np.bitwise_or.reduce(((a - np.uint64(8)) & m32) ^ ((a + np.uint64(8)) & m32)))
+    if not all((int(v) >> 23) == 127 for v in a):
+        return 22
+    lowest = max(int(highbit(np.array([(mb + mb) & 0xffffffff]))[0]), 23 - depth, 23 - 3 * (depth // 3))
+    raw = nodes.view(np.uint32).reshape(-1, 2)
+    s, parent = 22, 0
+    while s > lowest:
+        nd = raw[parent]
+        cs = 7 ^ (((int(a[0]) >> s) & 1) | (((int(a[1]) >> s) & 1) << 1) | (((int(a[2]) >> s) & 1) << 2))
+        masks = int(nd[0]) >> cs
+        if (masks & 0x10100) != 0x100:
+            break
+        parent += int(nd[1]) + cs
+        s -= 1
+    return s
+
+
+def simulate(ops, length, policy, lod, start=None):
+    """ops: (64, L) uint8 op codes, length: (64,) iterations per lane (0 = no ray), start: (64,) iterations a lane does not
+    execute (it starts below the root).  Returns issued VALU instructions."""
     n = len(length)
-    pos = np.zeros(n, np.int64)           # next iteration of each lane
+    pos = np.zeros(n, np.int64) if start is None else np.minimum(start.astype(np.int64), length)   # next iteration of each lane
     waiting_pop = np.zeros(n, bool)       # header + advance done, pop outstanding
     cost = 0.0
     blocks = np.zeros(4, np.int64)        # times the header / descend / advance / pop block was issued
@@ -74,6 +117,7 @@ def main():
     ap.add_argument("--band", type=int, default=32, help="render 1 / band of the 8-row blocks")
     ap.add_argument("--tiles", type=int, default=600)
     ap.add_argument("--threads", type=int, default=os.cpu_count() or 1)
+    ap.add_argument("--from-root", action="store_true", help="every ray from the root (the reference's walk, the kernels before round 3)")
     ap.add_argument("--dump", default="", help="write the block issue frequencies of the shipped policy as JSON (tools/issue_model.py reads it)")
     a = ap.parse_args()
     import cpuvoxelraycaster_amd as vrc
@@ -87,12 +131,27 @@ def main():
     LEN = 192
     trace = np.zeros((Hh, W, 8), np.uint16)
     ops = np.zeros((Hh, W, 8, LEN), np.uint8)
+    geo = np.zeros((Hh, W, 8, 8), np.float32)
     p = O.make_params(W, Hh, vrc.reference_light(depth), use_gi=1, use_samples=1, shadow_samples=1, row_block=8,
                       shard_index=a.band // 2, shard_count=a.band)
-    L.orc_render_frame_optrace.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(O.Camera),
-                                           C.POINTER(O.FrameParams), C.c_int, C.c_void_p, C.c_void_p, C.c_uint32]
-    L.orc_render_frame_optrace(O._ptr(nodes), depth, O._ptr(tex[0]), O._ptr(tex[1]), C.byref(ocam), C.byref(p), a.threads,
-                               O._ptr(trace), O._ptr(ops), LEN)
+    L.orc_render_frame_optrace_geo.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(O.Camera),
+                                               C.POINTER(O.FrameParams), C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    L.orc_render_frame_optrace_geo(O._ptr(nodes), depth, O._ptr(tex[0]), O._ptr(tex[1]), C.byref(ocam), C.byref(p), a.threads,
+                                   O._ptr(trace), O._ptr(ops), LEN, O._ptr(geo))
+    # where the kernel starts each ray (iterations not executed = 22 - start scale): camera rays next to the camera position
+    # on the camera cell's path, shadow and GI rays next to the primary hit, GI shadow rays next to the GI hit
+    f = np.float32
+    cam_pos = (np.asarray(cam.position, f) * (f(1.0) / f(1 << depth)) + f(1.0)).astype(f)
+    cam_scale = camera_path_scale(nodes, depth, cam_pos)
+    org, hpos, hscale, hkind = geo[..., 0:3], geo[..., 3:6], geo[..., 6].astype(np.int64), geo[..., 7]
+    skip = np.zeros((Hh, W, 8), np.int64)
+    s0 = start_scale_next_to(org[:, :, 0], np.broadcast_to(cam_pos, org[:, :, 0].shape), cam_scale)
+    skip[:, :, 0] = np.where(s0 < 22, 22 - s0, 0) if cam_scale < 22 else 0
+    for ray, prev in ((1, 0), (2, 0), (3, 2)):
+        s0 = start_scale_next_to(org[:, :, ray], hpos[:, :, prev], hscale[:, :, prev])
+        skip[:, :, ray] = np.where((s0 < 22) & (hkind[:, :, prev] != 0) & (trace[:, :, ray] > 0), 22 - s0, 0)
+    if a.from_root:
+        skip[:] = 0
     rows = [y for y in range(Hh) if (y // 8) % a.band == a.band // 2 and y // 8 * 8 + 8 <= Hh]
     blocks = sorted({y // 8 for y in rows})
     tiles = [(b, tx) for b in blocks for tx in range(W // 8)]
@@ -109,14 +168,17 @@ def main():
     shipped = "now (pop whenever a lane needs it)"
     stage_blocks = np.zeros((4, 4), np.int64)       # [stage][header, descend, advance, pop] of the shipped policy
     lane_iters = np.zeros(4, np.int64)
+    lane_skipped = np.zeros(4, np.int64)
     for (b, tx) in tiles:
         for st in range(4):
             o = ops[b * 8:b * 8 + 8, tx * 8:tx * 8 + 8, st].reshape(64, LEN)
             ln = trace[b * 8:b * 8 + 8, tx * 8:tx * 8 + 8, st].reshape(64).astype(np.int64)
-            lane_iters[st] += ln.sum()
+            sk = skip[b * 8:b * 8 + 8, tx * 8:tx * 8 + 8, st].reshape(64)
+            lane_iters[st] += (ln - np.minimum(sk, ln)).sum()
+            lane_skipped[st] += np.minimum(sk, ln).sum()
             for k, pol in policies.items():
                 pol.pop("_blocks", None)
-                c, r = simulate(o, ln, pol, lod=st >= 2)
+                c, r = simulate(o, ln, pol, lod=st >= 2, start=sk)
                 tot[k][st] += c
                 rounds[k][st] += r
                 if k == shipped:
@@ -127,7 +189,9 @@ def main():
                "tiles": len(tiles), "band": a.band,
                "stages": {names[i]: {"header": int(stage_blocks[i][0]), "descend": int(stage_blocks[i][1]),
                                      "advance": int(stage_blocks[i][2]), "pop": int(stage_blocks[i][3]),
-                                     "lane_iterations": int(lane_iters[i])} for i in range(4)},
+                                     "starts": len(tiles), "lane_iterations": int(lane_iters[i]),
+                                     "lane_iterations_not_executed": int(lane_skipped[i])} for i in range(4)},
+               "camera_start_scale": int(cam_scale),
                "note": "times each block of the walk loop (csrc/vrc_walk.h) is issued by a wave, summed over the sampled tiles: a "
                        "block is issued when any of the wave's 64 lanes needs it; from the oracle's per-iteration op traces "
                        "(tests/tools/path_schedule.py --dump)"}

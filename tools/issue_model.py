@@ -85,7 +85,7 @@ def macro_body(src, name):
 def strings_of(text):
     """the asm text a macro body contributes: its string literals, in order, with nested macro names left in place"""
     out = []
-    for tok in re.finditer(r'"((?:[^"\\]|\\.)*)"|\b(VRC_WALK_[A-Z_0-9]+|SPANPART|TMAXPART|COUNTPART|BIASPART)\b|/\*(.*?)\*/', text, re.S):
+    for tok in re.finditer(r'"((?:[^"\\]|\\.)*)"|\b(VRC_WALK_[A-Z_0-9]+|SPANPART|STARTPART|COUNTPART|BIASPART|ROWSH|ROWDOWN)\b|/\*(.*?)\*/', text, re.S):
         if tok.group(1) is not None:
             out.append(("str", tok.group(1).replace("\\n", "\n")))
         elif tok.group(2) is not None:
@@ -96,7 +96,7 @@ def strings_of(text):
 
 
 def expand(src, lod_mode, count_lane):
-    sub = {"SPANPART": "VRC_WALK_SPAN_NOLOD" if lod_mode == 0 else "VRC_WALK_SPAN_LOD",
+    sub = {"STARTPART": "VRC_WALK_START_BELOW","SPANPART": "VRC_WALK_SPAN_NOLOD" if lod_mode == 0 else "VRC_WALK_SPAN_LOD",
            "TMAXPART": "VRC_WALK_TMAX_NOLOD" if lod_mode == 0 else "VRC_WALK_TMAX_LOD",
            "COUNTPART": "VRC_WALK_COUNT_LANE" if count_lane else "VRC_WALK_COUNT_WAVE",
            "BIASPART": "VRC_WALK_BIAS_ADD" if lod_mode == 2 else "VRC_WALK_BIAS_NONE"}
@@ -113,7 +113,9 @@ def expand(src, lod_mode, count_lane):
                     res.append("\n;BLOCK " + val.strip(" -").split()[0] + "\n")
             else:
                 name = sub.get(val, val)
-                if name == "VRC_WALK_LOAD_NODE":
+                if name in ("ROWSH", "ROWDOWN"):          # macro arguments that are string literals (the stack's row stride)
+                    res.append("11" if name == "ROWSH" else "0xfffff800")
+                elif name == "VRC_WALK_LOAD_NODE":
                     res.extend(rec(load_default))
                 else:
                     res.extend(rec(macro_body(src, name)))
@@ -124,7 +126,8 @@ def expand(src, lod_mode, count_lane):
 def block_counts(lod_mode=0, count_lane=False):
     src = open(WALK).read()
     text = expand(src, lod_mode, count_lane)
-    blocks = {"prologue": {}, "header": {}, "descend": {}, "advance": {}, "pop": {}, "epilogue": {}}
+    blocks = {"prologue": {}, "header": {}, "descend": {}, "advance": {}, "pop": {}, "start": {}, "epilogue": {}}
+    in_start = False                  # the second half of the pop block is also the entry of rays that start below the root
     cur = "prologue"
     for line in text.split("\n"):
         line = line.strip()
@@ -136,6 +139,10 @@ def block_counts(lod_mode=0, count_lane=False):
             continue
         if re.match(r"Lwalk_next", line):
             cur = "header"            # the two loop-closing scalar instructions run every round
+            in_start = False
+            continue
+        if re.match(r"Lwalk_start", line):
+            in_start = True
             continue
         if re.match(r"Lwalk_done", line):
             cur = "epilogue"
@@ -148,6 +155,8 @@ def block_counts(lod_mode=0, count_lane=False):
             continue
         c = classify(op)
         blocks[cur][c] = blocks[cur].get(c, 0) + 1
+        if in_start:
+            blocks["start"][c] = blocks["start"].get(c, 0) + 1
     return blocks
 
 
@@ -157,8 +166,8 @@ def per_tile_sample(freq, counts_nolod, counts_lod):
     rounds = 0.0
     for stage, f in freq["stages"].items():
         counts = counts_lod if stage.startswith("GI") else counts_nolod   # the GI ray and its shadow ray are cast with a LOD coefficient
-        for blk in ("header", "descend", "advance", "pop"):
-            n = f[blk] / freq["tiles"]
+        for blk in ("header", "descend", "advance", "pop", "start"):
+            n = f.get(blk + "s" if blk == "start" else blk, 0) / freq["tiles"]
             for c, k in counts[blk].items():
                 tot[c] = tot.get(c, 0.0) + n * k
         rounds += f["header"] / freq["tiles"]
