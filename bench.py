@@ -486,6 +486,7 @@ def main():
         rays = sum(x.rays for x in sts)
         sum_complexity = sum(x.sum_complexity for x in sts)
         pixels = sum(x.pixels for x in sts)
+        iterations_not_executed = sum(x.iterations_not_executed for x in sts)
     st = _Sum
     # events around each launch: with one frame in flight that is the kernel's duration; with F launches sharing the chip
     # it spans ~F frame periods (and is what rocprofv3 --stats shows as the average duration), so the roofline prices the
@@ -694,8 +695,10 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         # roofline of the dominant kernel (k_render_sync*), this rank's launches:
         # algorithmic bytes per launch = 8 B per traversal-loop iteration (one LNode, lsvo.hpp:74)
-        # + one 32 B accumulator read-modify-write per pixel of the launch (raycaster.hpp:87-90)
-        my_steps_per_launch = st.sum_complexity / args.steps
+        # + one 32 B accumulator read-modify-write per pixel of the launch (raycaster.hpp:87-90).  Only the iterations the kernel
+        # EXECUTES are priced: a ray next to the previous hit starts below the root, and the descends from the root it leaves out
+        # (counted in sum_complexity, as the reference counts them) fetch nothing
+        my_steps_per_launch = (st.sum_complexity - st.iterations_not_executed) / args.steps
         my_pixels_per_launch = st.pixels / args.steps / spp
         alg_bytes = 8.0 * my_steps_per_launch + 32.0 * my_pixels_per_launch
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
@@ -715,8 +718,12 @@ def main():
                                  "(= the average duration rocprofv3 --stats reports for this command)"),
                 "kernel_ms_bracketed": round(kernel_ms_bracketed, 4),
                 "kernel_ms_max_rank": round(kernel_ms_max, 4), "algorithmic_bytes_per_launch": int(alg_bytes),
+                "loop_iterations_per_launch": {"counted": int(st.sum_complexity / args.steps),
+                                               "executed": int(my_steps_per_launch),
+                                               "note": "counted = sum of HitPoint::complexity (lsvo.hpp:73), equal to the reference's; executed = "
+                                                       "without the descends from the root that rays starting next to a hit leave out"},
                 "kernel_ms_render_only": (round(render_only_ms, 4) if render_only_ms is not None else None),
-                "achieved_is": "ALGORITHMIC bytes (SURVEY 8d: 8 B per walk-loop iteration + 32 B per pixel) / kernel time -- nominal by "
+                "achieved_is": "ALGORITHMIC bytes (SURVEY 8d: 8 B per walk-loop iteration EXECUTED + 32 B per pixel) / kernel time -- nominal by "
                                "construction: the tree is L1/L2-resident, see traffic_frac_of_peak, and the binding limit is VALU "
                                "instruction issue, see issue"}
         if rec:

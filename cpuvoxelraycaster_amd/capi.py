@@ -42,7 +42,7 @@ class FrameParams(C.Structure):
 
 class FrameStats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("sum_complexity", C.c_uint64),
-                ("primary_hits", C.c_uint64), ("pixels", C.c_uint64)]
+                ("primary_hits", C.c_uint64), ("pixels", C.c_uint64), ("iterations_not_executed", C.c_uint64)]
 
 
 # every symbol include/vrc.h declares: (restype, argtypes)

@@ -851,13 +851,14 @@ extern "C" int vrc_get_stats(vrc_renderer* r, vrc_frame_stats* out, int reset, v
 {
     if (!r || !out) return fail(VRC_ERR_INVALID, "vrc_get_stats: null argument");
     HIP_TRY(hipSetDevice(r->device));
-    std::vector<uint64_t> slots(vrc::VRC_STAT_SLOTS * 4u);
+    std::vector<uint64_t> slots(vrc::VRC_STAT_SLOTS * 8u);
     HIP_TRY(hipMemcpyAsync(slots.data(), r->d_stats, vrc::VRC_STATS_BYTES, hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-    uint64_t h[4] = {0, 0, 0, 0};
+    uint64_t h[5] = {0, 0, 0, 0, 0};
     for (uint32_t i = 0; i < vrc::VRC_STAT_SLOTS; ++i)
-        for (int k = 0; k < 4; ++k) h[k] += slots[4u * i + k];
+        for (int k = 0; k < 5; ++k) h[k] += slots[8u * i + k];
     out->rays = h[0]; out->sum_complexity = h[1]; out->primary_hits = h[2]; out->pixels = h[3];
+    out->iterations_not_executed = h[4];
     if (reset) {
         HIP_TRY(hipMemsetAsync(r->d_stats, 0, vrc::VRC_STATS_BYTES, (hipStream_t)stream));
         HIP_TRY(hipStreamSynchronize((hipStream_t)stream));

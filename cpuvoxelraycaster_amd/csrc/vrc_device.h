@@ -314,6 +314,10 @@ __device__ __forceinline__ void ray_run(Ray& r, bool active, const uint2* __rest
 // The same for callers that only total rays and iterations (the stage-synchronous frame kernels): books the call in the
 // wave's LDS counters -- ctr[0] += loop iterations of all lanes, ctr[1] += lanes that cast a ray -- and leaves
 // r.complexity alone.  One no-return LDS add pair by the first lane that ran; no per-lane counter stays live.
+// The stage-synchronous kernels keep, per wave, {iterations executed, rays, primary hits, pixel-samples} in four consecutive
+// u64 (16 of them for the workgroup's four waves), the camera path (64 B) after those, and then the waves' counts of
+// iterations NOT executed (rays that start below the root): ctr[VRC_CTR_NOT_EXECUTED] from a wave's own ctr.
+#define VRC_CTR_NOT_EXECUTED ((16u * 8u + 64u) / 8u - 3u * (threadIdx.x >> 6))
 __device__ __forceinline__ void book_walk(unsigned long long* ctr, uint32_t wave_steps)
 {
     // every lane that makes the call casts a ray (one that ray_setup rejected is a ray of complexity 0, as in the oracle)
@@ -360,8 +364,11 @@ __device__ __forceinline__ void ray_run_total(Ray& r, bool active, const uint2* 
 //   - s0 >= the scale of the hit (the deeper rows of the stack are not on the hit's path),
 //   - no multiple of 2^s0 ulps within 8 ulps of an origin coordinate: the comparisons test the centre planes of the cells
 //     above (c - o) * t_coef-wise, their rounding error is below 4.5 ulps of the coordinate,
-// or a value >= 22 when there is none (the ray then starts at the root).  The caller promises |d| = 1 and an LOD coefficient
-// <= 0.5 with bias 0: then the LOD test (:82) cannot fire in a cell that holds the origin (tc_max <= sqrt(3) * scale_f).
+// or a value >= 22 when there is none (the ray then starts at the root).  A ray cast with an LOD coefficient needs one thing
+// more: the LOD test (:82) must not fire in a cell that holds the origin.  tc_max <= scale_f / max|d_i| there, so with bias 0
+// it cannot when coef < max|d_i| -- start_scale_next_to_lod, for the frame kernels' coef = 0.5: every unit vector has
+// max|d_i| >= 0.577; a direction that collapsed (the light at 1e30: normalize() returns 0, :44-46 make it +-EPS per axis, and
+// the reference's first iteration IS an LOD hit) starts at the root.
 // oracle/vrc_walk_model.c restates this on the CPU and tests/test_walk_model.py holds it to the oracle ray by ray.
 __device__ __forceinline__ uint32_t start_scale_next_to(float ox, float oy, float oz, float hx, float hy, float hz, uint32_t hit_scale)
 {
@@ -371,6 +378,14 @@ __device__ __forceinline__ uint32_t start_scale_next_to(float ox, float oy, floa
     const uint32_t bits = db | (mb + mb);
     const int s = 31 - __clz((int)bits);                  // -1 for no bit at all
     return (uint32_t)max(s, (int)hit_scale);
+}
+
+// ... for a ray cast with LOD coefficient 0.5 and bias 0; (dx, dy, dz) = the direction as ray_setup conditioned it
+__device__ __forceinline__ uint32_t start_scale_next_to_lod(float ox, float oy, float oz, float hx, float hy, float hz, uint32_t hit_scale,
+                                                            float dx, float dy, float dz)
+{
+    const uint32_t s0 = start_scale_next_to(ox, oy, oz, hx, hy, hz, hit_scale);
+    return fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz)) > 0.55f ? s0 : (uint32_t)(SVO_MAX - 1);
 }
 
 // The rows of one lane's stack column copied to another column: a walk that starts below the root on the copy leaves the
@@ -456,6 +471,15 @@ __device__ __forceinline__ void ray_start_below(Ray& r, uint32_t s0, float ox, f
 #endif
 }
 
+// :73 for the iterations a ray that starts below the root does not execute (call before the walk: r.scale is its start scale)
+__device__ __forceinline__ uint32_t book_not_executed(unsigned long long* ctr, bool active, const Ray& r)
+{
+    const uint32_t not_executed = (uint32_t)(SVO_MAX - 1 - r.scale);
+    if (active && not_executed)
+        __hip_atomic_fetch_add(ctr + VRC_CTR_NOT_EXECUTED, (unsigned long long)not_executed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    return active ? not_executed : 0u;
+}
+
 // ray_run_total for a ray that may start below the root (ray_start_below)
 template <int STRIDE, int LOD_MODE>
 __device__ __forceinline__ void ray_run_total_below(Ray& r, bool active, const uint2* __restrict__ nodes, stack_t* stk,
@@ -465,9 +489,7 @@ __device__ __forceinline__ void ray_run_total_below(Ray& r, bool active, const u
     ray_run_total<STRIDE, LOD_MODE>(r, active, nodes, stk, depth, coef, bias, ctr);     // from the root: the same walk
 #else
     static_assert(STRIDE == 256 || STRIDE == 512, "vrc_walk.h addresses LDS stack rows of 256 lanes, 1 or 2 KiB apart");
-    const uint32_t not_executed = (uint32_t)(SVO_MAX - 1 - r.scale);
-    if (active && not_executed)                           // :73 for the iterations this lane does not execute
-        __hip_atomic_fetch_add(ctr + 0, (unsigned long long)not_executed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    book_not_executed(ctr, active, r);
     const uint32_t wave_steps = ray_walk<LOD_MODE, false, true, STRIDE == 512>(r, active, nodes, stk, depth, coef, bias);
     book_walk(ctr, wave_steps);
 #endif

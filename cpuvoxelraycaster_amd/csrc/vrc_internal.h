@@ -37,10 +37,10 @@ int require_device(int device, int* cu_count);
 
 // Counters and queue heads are spread out: thousands of waves ending within microseconds of each other on one
 // 128-byte line serialise in the L2 atomic unit (~88 atomics/us per line) and stretch the end of a launch.
-constexpr uint32_t VRC_STAT_SLOTS = 1024;      // 32-byte slots, slot = workgroup % VRC_STAT_SLOTS
+constexpr uint32_t VRC_STAT_SLOTS = 1024;      // 64-byte slots (8 x u64, 5 used), slot = workgroup % VRC_STAT_SLOTS
 constexpr uint32_t VRC_QUEUE_HEADS = 8;
 constexpr uint32_t VRC_QUEUE_STRIDE = 1024;    // u32 between heads (4 KiB: separate L2 channels)
-constexpr uint32_t VRC_STATS_BYTES = VRC_STAT_SLOTS * 32u;
+constexpr uint32_t VRC_STATS_BYTES = VRC_STAT_SLOTS * 64u;
 constexpr uint32_t VRC_QUEUE_BYTES = VRC_QUEUE_HEADS * VRC_QUEUE_STRIDE * 4u;   // one set of heads; a renderer has two
 
 // by-value kernel argument of k_render
@@ -50,7 +50,7 @@ struct FrameArgs {
     uint8_t* image;           // RGBA8 w*h
     uint32_t* accum;          // 4 x u32 per pixel
     vrc_hit* prim;            // optional primary-hit capture
-    uint64_t* stats;          // VRC_STAT_SLOTS x {rays, sum_complexity, primary_hits, pixels}; summed by vrc_get_stats
+    uint64_t* stats;          // VRC_STAT_SLOTS x {rays, sum_complexity, primary_hits, pixels, iterations not executed, -, -, -}; summed by vrc_get_stats
     uint32_t* queue;          // work-queue heads, VRC_QUEUE_STRIDE u32 apart
     uint32_t depth, width, height;
     uint32_t n_items;         // work items (8x8-tile order over this shard's rows)
@@ -84,17 +84,18 @@ hipError_t launch_grid_cast(const uint8_t* cells, int X, int Y, int Z, uint64_t 
 uint32_t tile_wave_lds_bytes();       // LDS job pool per wave of k_render_tile
 uint32_t tile_max_blocks_per_cu();    // register-limited workgroups per CU of k_render_tile
 uint32_t sync_max_blocks_per_cu();    // ... of k_render_sync
-// The stage-synchronous kernels exist in several builds by waves per SIMD: 6 (80 VGPRs; all of them), 7 (72; the one-bounce
-// kernels) and 8 (64; the pinhole kernels).  More waves hide more latency, make the end of a launch more ragged and leave
-// fewer registers (spills); which wins depends on the launch.  Round 3, tools/sweep_waves.sh at camera pitch 0 / -0.5 / -1.2
-// (profiles/r03/sweep_waves.txt, sweep_waves_c4.txt), ms per frame at pitch -0.5:
-//   pinhole + GI (C3), one launch at a time (automatic chunk)   6: 1.209   7: 1.163   8: 1.209      (C5: 16.29 / 15.58 / 15.57)
-//   pinhole + GI (C3), whole-spp units, three frames in flight  6: 1.062   7: 1.044   8: 1.039      (C5: 15.60 / 15.32 / 15.14)
-//   lens (DOF) + GI (C4), three frames in flight                6: 1.307   7: 1.294   8: 1.327
-//   lens (DOF) + GI (C4), one at a time                         6: 1.422   7: 1.446   8: 1.410      (pitch 0: 0.910 / 0.942 / 0.926)
-//   short launch (C2: 1280 x 720, primary + shadow, 1 spp)      6: 0.073   7: 0.075   8: 0.082
-// The choice is the same at all three pitches.  sync_waves_for picks by that table; a caller's
-// vrc_renderer_set_tuning(blocks_per_cu) overrides it.
+// The stage-synchronous kernels are built for 6 waves per SIMD (80 VGPRs), the lens one-bounce kernel also for 7 (72).
+// Rounds 2 and 3 shipped 7- and 8-wave builds of the pinhole kernels too, picked by a table (profiles/r03/sweep_waves.txt:
+// the 8-wave build won C3 with frames in flight by 2 %).  With walks that start below the root -- fewer iterations, two
+// stacks, more state per ray -- the 6-wave build ties or beats them on every configuration, pose and shard size
+// (tools/sweep_waves.sh -> profiles/r03/sweep_waves_below.txt, shard_inflight_below.txt; ms per frame at pitch -0.5):
+//   pinhole + GI (C3), whole-spp units, three frames in flight  6: 0.978   7: 0.981   8: 0.981      (C5, depth 10: 6 only)
+//   pinhole + GI (C3), one launch at a time (automatic chunk)   6: 1.125   7: 1.121   8: 1.162      (pitch 0: 0.770 / 0.786 / 0.814)
+//   lens (DOF) + GI (C4), three frames in flight                6: 1.250   7: 1.232
+//   lens (DOF) + GI (C4), one at a time                         6: 1.372   7: 1.348                 (pitch 0: 0.889 / 0.899)
+//   short launch (C2: 1280 x 720, primary + shadow, 1 spp)      6: 0.073   7: 0.079   8: 0.087
+// so they are gone (and with them their register spills: the 6-wave pinhole kernel has one).  sync_waves_for: 6, the lens
+// kernel 7 with whole-spp units; a caller's vrc_renderer_set_tuning(blocks_per_cu) >= 7 selects the lens kernel's 7-wave build.
 uint32_t sync_waves_for(bool pinhole, bool one_bounce, bool use_gi, bool whole_spp_units, uint64_t pixel_samples, uint32_t requested);
 bool camera_is_pinhole(const vrc_camera& cam);   // the host's predicate for the pinhole kernels (see launch_render)
 hipError_t launch_render(const FrameArgs& a, uint32_t grid_blocks, int kernel, hipStream_t st, const char** launched);

@@ -458,7 +458,7 @@ k_render(const FrameArgs a)
         s_pix += __shfl_down(s_pix, off);
     }
     if (__lane_id() == 0u) {
-        uint64_t* slot = a.stats + 4u * (blockIdx.x % VRC_STAT_SLOTS);
+        uint64_t* slot = a.stats + 8u * (blockIdx.x % VRC_STAT_SLOTS);
         atomicAdd(reinterpret_cast<unsigned long long*>(slot + 0), (unsigned long long)s_rays);
         atomicAdd(reinterpret_cast<unsigned long long*>(slot + 1), (unsigned long long)s_steps);
         atomicAdd(reinterpret_cast<unsigned long long*>(slot + 2), (unsigned long long)s_hits);
@@ -803,7 +803,7 @@ k_render_tile(const FrameArgs a)
         s_pix += __shfl_down(s_pix, off);
     }
     if (lane == 0u) {
-        uint64_t* slot = a.stats + 4u * (blockIdx.x % VRC_STAT_SLOTS);
+        uint64_t* slot = a.stats + 8u * (blockIdx.x % VRC_STAT_SLOTS);
         atomicAdd(reinterpret_cast<unsigned long long*>(slot + 0), (unsigned long long)s_rays);
         atomicAdd(reinterpret_cast<unsigned long long*>(slot + 1), (unsigned long long)s_steps);
         atomicAdd(reinterpret_cast<unsigned long long*>(slot + 2), (unsigned long long)s_hits);
@@ -847,10 +847,11 @@ __device__ __forceinline__ uint32_t probe_wave_max(uint32_t v)
 // raycaster.hpp:169-207 getGlobalIllumination for one pixel-sample (+ the nested second bounce of the extension): GI
 // ray from the point (bp, bn), cast with LOD coefficient 0.5; if it hits, a shadow ray from the GI hit towards the
 // light.  Called by all lanes of a wave whose pixel-sample has a primary hit (`in exec`); the two walks are wave-wide.
-// `stk_hit` holds the path to the point's hit (the stack its walk left), `stk` is the stack the chain's walks use: the GI ray
-// starts below the root on a copy of that path, the GI shadow ray on what the GI walk left (vrc_device.h, ray_start_below).
+// `stk_hit` holds the path to the point's hit (the stack its walk left); the chain's walks use the other stack (its rows lie
+// VRC_RENDER_BLOCK entries further): the GI ray starts below the root on a copy of that path, the GI shadow ray on what the
+// GI walk left (vrc_device.h, ray_start_below).
 template <bool ONE_BOUNCE>   // true: gi_bounces == 1 is known (the reference's semantics), the chain is straight-line code
-__device__ __forceinline__ float gi_chain(const uint2* __restrict__ nodes, stack_t* stk, const stack_t* stk_hit, const uint32_t base_scale,
+__device__ __forceinline__ float gi_chain(const uint2* __restrict__ nodes, stack_t* const stk_hit, const uint32_t base_scale,
                                           const uint2 root, const int depth,
                                           const float n_normalizer, const float lx, const float ly, const float lz,
                                           const uint32_t gi_bounces_rt, const uint32_t seed, const uint32_t fr, const uint32_t pix,
@@ -858,6 +859,7 @@ __device__ __forceinline__ float gi_chain(const uint2* __restrict__ nodes, stack
                                           unsigned long long* ctr)
 {
     const uint32_t gi_bounces = ONE_BOUNCE ? 1u : gi_bounces_rt;
+    stack_t* const stk = stk_hit + VRC_RENDER_BLOCK;
     Ray r;
     bool active;
     float ox, oy, oz, dx, dy, dz;
@@ -884,7 +886,7 @@ __device__ __forceinline__ float gi_chain(const uint2* __restrict__ nodes, stack
         active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
         if (level == 0u) {     // (a deeper level starts at the root: the GI shadow walk has used the stack since its hit)
             copy_stack<VRC_SYNC_ROW>(stk, stk_hit, depth);
-            ray_start_below(r, start_scale_next_to(ox, oy, oz, base_px, base_py, base_pz, base_scale), ox, oy, oz);
+            ray_start_below(r, start_scale_next_to_lod(ox, oy, oz, base_px, base_py, base_pz, base_scale, dx, dy, dz), ox, oy, oz);
         }
         ray_run_total_below<VRC_SYNC_ROW, 1>(r, active, nodes, stk, depth, 0.5f, 0.0f, ctr);   // :194
         Hit g;
@@ -899,7 +901,7 @@ __device__ __forceinline__ float gi_chain(const uint2* __restrict__ nodes, stack
             const float dotl = dot3(g.nx, g.ny, g.nz, dx, dy, dz);         // :200
             const float contrib = 1000000.0f * smin(0.5f, smax(0.0f, dotl) * dot_gi);   // :201
             active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
-            ray_start_below(r, start_scale_next_to(ox, oy, oz, g.px, g.py, g.pz, (g.hit >> 16) & 0xffu), ox, oy, oz);
+            ray_start_below(r, start_scale_next_to_lod(ox, oy, oz, g.px, g.py, g.pz, (g.hit >> 16) & 0xffu, dx, dy, dz), ox, oy, oz);
             ray_run_total_below<VRC_SYNC_ROW, 1>(r, active, nodes, stk, depth, 0.5f, 0.0f, ctr);   // :198
             if (!r.kind) { if (level == 0u) acc[0] += contrib; else acc[1] += contrib; }
             if (level + 1u < gi_bounces) {
@@ -920,7 +922,7 @@ __device__ __forceinline__ float gi_chain(const uint2* __restrict__ nodes, stack
 // rejects gi_bounces > 2, launch_render sends gi_bounces <= 1 to the one-bounce kernels).  Same operations in the same
 // order as gi_chain<false> with gi_bounces = 2 -- level 0 from the primary hit with draws 2, 3, level 1 from the GI hit with
 // draws 4, 5, gi = max(0, acc0 + dot_gi0 * max(0, acc1)) -- without the loop-carried level / draw / base state.
-__device__ __forceinline__ float gi_two_levels(const uint2* __restrict__ nodes, stack_t* stk, const stack_t* stk_hit, const uint32_t base_scale,
+__device__ __forceinline__ float gi_two_levels(const uint2* __restrict__ nodes, stack_t* const stk_hit, const uint32_t base_scale,
                                                const uint2 root, const int depth,
                                                const float n_normalizer, const float lx, const float ly, const float lz,
                                                const uint32_t seed, const uint32_t fr, const uint32_t pix,
@@ -928,6 +930,7 @@ __device__ __forceinline__ float gi_two_levels(const uint2* __restrict__ nodes, 
                                                const float b0nx, const float b0ny, const float b0nz, unsigned long long* ctr)
 {
     float acc0 = 0.0f, acc1 = 0.0f, dgi0 = 0.0f;
+    stack_t* const stk = stk_hit + VRC_RENDER_BLOCK;
     Ray r;
     bool active;
     float ox, oy, oz, dx, dy, dz;
@@ -948,7 +951,7 @@ __device__ __forceinline__ float gi_two_levels(const uint2* __restrict__ nodes, 
         dgi0 = dot3(dx, dy, dz, b0nx, b0ny, b0nz);                        // :193
         active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
         copy_stack<VRC_SYNC_ROW>(stk, stk_hit, depth);
-        ray_start_below(r, start_scale_next_to(ox, oy, oz, b0px, b0py, b0pz, base_scale), ox, oy, oz);
+        ray_start_below(r, start_scale_next_to_lod(ox, oy, oz, b0px, b0py, b0pz, base_scale, dx, dy, dz), ox, oy, oz);
         ray_run_total_below<VRC_SYNC_ROW, 1>(r, active, nodes, stk, depth, 0.5f, 0.0f, ctr);   // :194
     }
     Hit g;
@@ -962,7 +965,7 @@ __device__ __forceinline__ float gi_two_levels(const uint2* __restrict__ nodes, 
         const float dotl = dot3(g.nx, g.ny, g.nz, dx, dy, dz);             // :200
         const float contrib = 1000000.0f * smin(0.5f, smax(0.0f, dotl) * dgi0);   // :201
         active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
-        ray_start_below(r, start_scale_next_to(ox, oy, oz, g.px, g.py, g.pz, (g.hit >> 16) & 0xffu), ox, oy, oz);
+        ray_start_below(r, start_scale_next_to_lod(ox, oy, oz, g.px, g.py, g.pz, (g.hit >> 16) & 0xffu, dx, dy, dz), ox, oy, oz);
         ray_run_total_below<VRC_SYNC_ROW, 1>(r, active, nodes, stk, depth, 0.5f, 0.0f, ctr);   // :198
         if (!r.kind) acc0 += contrib;
         // ---- level 1: the same from the GI hit
@@ -994,7 +997,7 @@ __device__ __forceinline__ float gi_two_levels(const uint2* __restrict__ nodes, 
             const float dotl1 = dot3(g1.nx, g1.ny, g1.nz, dx, dy, dz);
             const float contrib1 = 1000000.0f * smin(0.5f, smax(0.0f, dotl1) * dgi1);
             active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
-            ray_start_below(r, start_scale_next_to(ox, oy, oz, g1.px, g1.py, g1.pz, (g1.hit >> 16) & 0xffu), ox, oy, oz);
+            ray_start_below(r, start_scale_next_to_lod(ox, oy, oz, g1.px, g1.py, g1.pz, (g1.hit >> 16) & 0xffu, dx, dy, dz), ox, oy, oz);
             ray_run_total_below<VRC_SYNC_ROW, 1>(r, active, nodes, stk, depth, 0.5f, 0.0f, ctr);
             if (!r.kind) acc1 += contrib1;
         }
@@ -1036,10 +1039,11 @@ __device__ __forceinline__ uint32_t albedo_of(const uint8_t* tex, const Hit& h)
 template <bool PINHOLE, bool ONE_BOUNCE, bool FUSED>
 __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
 {
-    // [depth][2][256] two stacks, their rows interleaved | 1536 B textures | 4 waves x 4 counters | camera path (16 entries)
+    // [depth][2][256] two stacks, their rows interleaved | 1536 B textures | 4 waves x 4 counters | camera path (16 entries) |
+    // 4 waves' count of iterations not executed
     extern __shared__ stack_t lds_dyn[];
     stack_t* stk = lds_dyn + threadIdx.x;                              // the path to the primary hit, kept until the next primary walk
-    stack_t* stk2 = stk + VRC_RENDER_BLOCK;                            // secondary rays: a copy of that path, then their own
+    // (secondary rays use the other stack, stk + VRC_RENDER_BLOCK: a copy of that path, then their own)
     uint8_t* tex = reinterpret_cast<uint8_t*>(lds_dyn + 2u * a.depth * VRC_RENDER_BLOCK);
     const uint32_t lane = threadIdx.x & 63u;
     for (uint32_t i = threadIdx.x; i < 1536u / 4u; i += VRC_RENDER_BLOCK)
@@ -1048,6 +1052,7 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
     // no-return LDS adds, so that no per-lane counter is live across the walks (the kernel is at its register budget)
     unsigned long long* const ctr = reinterpret_cast<unsigned long long*>(tex + 1536) + 4u * (threadIdx.x >> 6);
     if (lane < 4u) ctr[lane] = 0ull;
+    if (lane == 4u) ctr[VRC_CTR_NOT_EXECUTED] = 0ull;
     const uint2* __restrict__ nodes = a.nodes;
     const int depth = (int)a.depth;
     // the path from the root to the camera's cell (vrc_device.h, camera_path): camera rays start at its end
@@ -1169,7 +1174,7 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
             const bool reuse = ka->reuse_invariant != 0u;
             const uint32_t n_walks = reuse ? 1u : n_samples, n_shadow_walks = reuse ? 1u : n_samples * shadow_samples;
             bool hit = false;
-            uint32_t albedo = 0u, hit_scale = 0u;
+            uint32_t albedo = 0u;                                              // | scale of the hit << 24
             float light_intensity = 0.0f;
             float hpx = 0.0f, hpy = 0.0f, hpz = 0.0f, hnx = 0.0f, hny = 0.0f, hnz = 0.0f;
             if (valid) {
@@ -1196,8 +1201,9 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
                     r = r0;
                     copy_camera_path<VRC_SYNC_ROW>(stk, cam_path, depth, cam_scale);
                     if (a.prim) {                                                   // the capture records the ray's own complexity
+                        const uint32_t not_executed = book_not_executed(ctr, active, r);
                         ray_run<VRC_SYNC_ROW, 0, true>(r, active, nodes, stk, depth, 0.0f, 0.0f);
-                        book_walk_lanes(ctr, r.complexity);
+                        book_walk_lanes(ctr, r.complexity - not_executed);
                     } else {
                         ray_run_total_below<VRC_SYNC_ROW, 0>(r, active, nodes, stk, depth, 0.0f, 0.0f, ctr);
                     }
@@ -1214,7 +1220,7 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
 #endif
                 if (h.hit) {
                     hit = true;
-                    albedo = albedo_of(tex, h);                                     // raycaster.hpp:141-145
+                    albedo = albedo_of(tex, h) | (h.hit >> 16 << 24);               // raycaster.hpp:141-145
                     hpx = h.px; hpy = h.py; hpz = h.pz; hnx = h.nx; hny = h.ny; hnz = h.nz;
                     // raycaster.hpp:139,150-158 shadow ray(s): the reference re-casts the identical ray
                     ox = h.px + h.nx * inv_size * 0.001f;
@@ -1224,12 +1230,11 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
                     normalize3(dx, dy, dz);
                     const float lit = smax(0.0f, dot3(dx, dy, dz, h.nx, h.ny, h.nz));           // :156
                     active = ray_setup(r0, root, ox, oy, oz, dx, dy, dz);
-                    hit_scale = (h.hit >> 16) & 0xffu;
-                    ray_start_below(r0, start_scale_next_to(ox, oy, oz, h.px, h.py, h.pz, hit_scale), ox, oy, oz);
+                    ray_start_below(r0, start_scale_next_to(ox, oy, oz, h.px, h.py, h.pz, h.hit >> 16), ox, oy, oz);
                     for (uint32_t k = n_shadow_walks; k--;) {
                         r = r0;
-                        copy_stack<VRC_SYNC_ROW>(stk2, stk, depth);
-                        ray_run_total_below<VRC_SYNC_ROW, 0>(r, active, nodes, stk2, depth, 0.0f, 0.0f, ctr);
+                        copy_stack<VRC_SYNC_ROW>(stk + VRC_RENDER_BLOCK, stk, depth);
+                        ray_run_total_below<VRC_SYNC_ROW, 0>(r, active, nodes, stk + VRC_RENDER_BLOCK, depth, 0.0f, 0.0f, ctr);
                     }
                     if (!r.kind) light_intensity = lit;                                      // :155-157
                 }
@@ -1242,10 +1247,10 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
                         float gi_intensity = 0.0f;
                         if (a.p.use_gi) {
                             if constexpr (ONE_BOUNCE)
-                                gi_intensity = gi_chain<ONE_BOUNCE>(nodes, stk2, stk, hit_scale, root, depth, n_normalizer, lx, ly, lz, gi_bounces, a.p.seed,
+                                gi_intensity = gi_chain<ONE_BOUNCE>(nodes, stk, albedo >> 24, root, depth, n_normalizer, lx, ly, lz, gi_bounces, a.p.seed,
                                                     a.p.frame_index + sample, pix, hpx, hpy, hpz, hnx, hny, hnz, ctr);
                             else
-                                gi_intensity = gi_two_levels(nodes, stk2, stk, hit_scale, root, depth, n_normalizer, lx, ly, lz, a.p.seed,
+                                gi_intensity = gi_two_levels(nodes, stk, albedo >> 24, root, depth, n_normalizer, lx, ly, lz, a.p.seed,
                                                     a.p.frame_index + sample, pix, hpx, hpy, hpz, hnx, hny, hnz, ctr);
                         }
                         color = color_mult(albedo, smin(1.0f, smax(0.0f, light_intensity + gi_intensity)));   // :163
@@ -1302,8 +1307,9 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
                                                            (a.cam.position[1] + 0.0f) * inv_size + 1.0f,
                                                            (a.cam.position[2] + 0.0f) * inv_size + 1.0f, cam_scale), ox, oy, oz);
                     if (a.prim) {                                                   // the capture records the ray's own complexity
+                        const uint32_t not_executed = book_not_executed(ctr, active, r);
                         ray_run<VRC_SYNC_ROW, 0, true>(r, active, nodes, stk, depth, 0.0f, 0.0f);
-                        book_walk_lanes(ctr, r.complexity);
+                        book_walk_lanes(ctr, r.complexity - not_executed);
                     } else {
                         ray_run_total_below<VRC_SYNC_ROW, 0>(r, active, nodes, stk, depth, 0.0f, 0.0f, ctr);
                     }
@@ -1331,9 +1337,9 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
                             normalize3(dx, dy, dz);
                             const float lit = smax(0.0f, dot3(dx, dy, dz, h.nx, h.ny, h.nz));       // :156
                             active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
-                            copy_stack<VRC_SYNC_ROW>(stk2, stk, depth);
+                            copy_stack<VRC_SYNC_ROW>(stk + VRC_RENDER_BLOCK, stk, depth);
                             ray_start_below(r, start_scale_next_to(ox, oy, oz, h.px, h.py, h.pz, (h.hit >> 16) & 0xffu), ox, oy, oz);
-                            ray_run_total_below<VRC_SYNC_ROW, 0>(r, active, nodes, stk2, depth, 0.0f, 0.0f, ctr);
+                            ray_run_total_below<VRC_SYNC_ROW, 0>(r, active, nodes, stk + VRC_RENDER_BLOCK, depth, 0.0f, 0.0f, ctr);
                             VRC_PROBE_WALK(r, 1)
                             if (!r.kind) light_intensity = lit;                                  // :155-157
                         }
@@ -1341,10 +1347,10 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
                         float gi_intensity = 0.0f;
                         if (a.p.use_gi) {
                             if constexpr (ONE_BOUNCE)
-                                gi_intensity = gi_chain<ONE_BOUNCE>(nodes, stk2, stk, (h.hit >> 16) & 0xffu, root, depth, n_normalizer, lx, ly, lz, gi_bounces, a.p.seed, fr, pix,
+                                gi_intensity = gi_chain<ONE_BOUNCE>(nodes, stk, (h.hit >> 16) & 0xffu, root, depth, n_normalizer, lx, ly, lz, gi_bounces, a.p.seed, fr, pix,
                                                     h.px, h.py, h.pz, h.nx, h.ny, h.nz, ctr);
                             else
-                                gi_intensity = gi_two_levels(nodes, stk2, stk, (h.hit >> 16) & 0xffu, root, depth, n_normalizer, lx, ly, lz, a.p.seed, fr, pix,
+                                gi_intensity = gi_two_levels(nodes, stk, (h.hit >> 16) & 0xffu, root, depth, n_normalizer, lx, ly, lz, a.p.seed, fr, pix,
                                                     h.px, h.py, h.pz, h.nx, h.ny, h.nz, ctr);
                         }
                         color = color_mult(albedo, smin(1.0f, smax(0.0f, light_intensity + gi_intensity)));   // :163
@@ -1434,11 +1440,12 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
         s_pix += __shfl_down(s_pix, off);
     }
     if (lane == 0u) {
-        uint64_t* slot = a.stats + 4u * (blockIdx.x % VRC_STAT_SLOTS);
+        uint64_t* slot = a.stats + 8u * (blockIdx.x % VRC_STAT_SLOTS);
         atomicAdd(reinterpret_cast<unsigned long long*>(slot + 0), ctr[1]);
-        atomicAdd(reinterpret_cast<unsigned long long*>(slot + 1), ctr[0]);
+        atomicAdd(reinterpret_cast<unsigned long long*>(slot + 1), ctr[0] + ctr[VRC_CTR_NOT_EXECUTED]);
         atomicAdd(reinterpret_cast<unsigned long long*>(slot + 2), (unsigned long long)s_hits + ctr[2]);
         atomicAdd(reinterpret_cast<unsigned long long*>(slot + 3), (unsigned long long)s_pix + ctr[3]);
+        atomicAdd(reinterpret_cast<unsigned long long*>(slot + 4), ctr[VRC_CTR_NOT_EXECUTED]);
     }
 }
 
@@ -1461,17 +1468,11 @@ VRC_SYNC_KERNEL(k_render_sync_resolved, false, true, true, VRC_SYNC_MIN_WAVES)
 VRC_SYNC_KERNEL(k_render_sync2_resolved, false, false, true, VRC_SYNC_MIN_WAVES)
 VRC_SYNC_KERNEL(k_render_sync_pinhole_resolved, true, true, true, VRC_SYNC_MIN_WAVES)
 VRC_SYNC_KERNEL(k_render_sync_pinhole2_resolved, true, false, true, VRC_SYNC_MIN_WAVES)
-// the one-bounce kernels at 7 and 8 waves per SIMD (vrc_internal.h: sync_waves_for)
-VRC_SYNC_KERNEL(k_render_sync_pinhole_w7, true, true, false, 7)
-VRC_SYNC_KERNEL(k_render_sync_pinhole_resolved_w7, true, true, true, 7)
-VRC_SYNC_KERNEL(k_render_sync_pinhole_w8, true, true, false, 8)
-VRC_SYNC_KERNEL(k_render_sync_pinhole_resolved_w8, true, true, true, 8)
-// ... the lens (DOF) one-bounce kernel at 7: at 64 registers it spills too much to gain from the eighth wave
+// the lens (DOF) one-bounce kernel also at 7 waves per SIMD (vrc_internal.h: sync_waves_for).  Rounds 2 and 3 shipped pinhole
+// builds for 7 and 8 waves as well; since the walks start below the root (fewer, less coherent iterations; two stacks) the
+// 6-wave build ties or beats them on every configuration and pose (profiles/r03/sweep_waves_below.txt), without their spills.
 VRC_SYNC_KERNEL(k_render_sync_w7, false, true, false, 7)
 VRC_SYNC_KERNEL(k_render_sync_resolved_w7, false, true, true, 7)
-// ... and the pinhole kernels of the 2-bounce extension at 8
-VRC_SYNC_KERNEL(k_render_sync_pinhole2_w8, true, false, false, 8)
-VRC_SYNC_KERNEL(k_render_sync_pinhole2_resolved_w8, true, false, true, 8)
 #undef VRC_SYNC_KERNEL
 
 // ---------------------------------------------------------------------------
@@ -1650,19 +1651,12 @@ uint32_t tile_max_blocks_per_cu() { return VRC_TILE_MIN_WAVES; }
 uint32_t sync_max_blocks_per_cu() { return VRC_SYNC_MIN_WAVES; }
 uint32_t sync_waves_for(bool pinhole, bool one_bounce, bool use_gi, bool whole_spp_units, uint64_t pixel_samples, uint32_t requested)
 {
-    // the builds that exist: 6 for every kernel; pinhole one-bounce 7 and 8; lens one-bounce 7; pinhole two-bounce 8
-    if (!one_bounce && !pinhole) return VRC_SYNC_MIN_WAVES;            // 2-bounce extension with a lens: the one build
-    if (requested) {                                                   // the caller's choice, rounded down to a build that exists
-        if (!one_bounce) return requested >= 8u ? 8u : VRC_SYNC_MIN_WAVES;
-        if (!pinhole) return requested >= 7u ? 7u : VRC_SYNC_MIN_WAVES;
-        return requested >= 8u ? 8u : (requested == 7u ? 7u : VRC_SYNC_MIN_WAVES);
-    }
-    // tools/sweep_waves.sh (profiles/r03/sweep_waves.txt: C2..C5 x pitch 0 / -0.5 / -1.2 x frames in flight 3 / 1)
-    if (!one_bounce) return whole_spp_units ? 8u : VRC_SYNC_MIN_WAVES;
-    if (!pinhole) return whole_spp_units ? 7u : VRC_SYNC_MIN_WAVES;   // lens: 7 by 1-2.4 % with frames in flight, 6 alone on the chip
-    if (whole_spp_units) return 8u;                                    // also on an eighth of the frame (tools/shard_inflight.py)
-    if (pixel_samples * (use_gi ? 2u : 1u) < (4ull << 20)) return VRC_SYNC_MIN_WAVES;   // short launch (C2)
-    return use_gi ? 7u : VRC_SYNC_MIN_WAVES;
+    // the builds that exist: 6 for every kernel; the lens one-bounce kernel also 7
+    (void)use_gi; (void)pixel_samples;
+    if (pinhole || !one_bounce) return VRC_SYNC_MIN_WAVES;
+    if (requested) return requested >= 7u ? 7u : VRC_SYNC_MIN_WAVES;   // the caller's choice, rounded down to a build that exists
+    // tools/sweep_waves.sh (profiles/r03/sweep_waves_below.txt: C2..C5 x pitch 0 / -0.5 / -1.2 x frames in flight 3 / 1)
+    return whole_spp_units ? 7u : VRC_SYNC_MIN_WAVES;                  // lens: 7 by 1-1.5 % with frames in flight, 6 alone on the chip
 }
 
 bool camera_is_pinhole(const vrc_camera& cam)
@@ -1692,17 +1686,14 @@ hipError_t launch_render(const FrameArgs& a, uint32_t grid_blocks, int kernel, h
         const size_t lds = (size_t)a.depth * VRC_RENDER_BLOCK * sizeof(stack_t) + 4 * TILE_WAVE_LDS + 1536;
         hipLaunchKernelGGL(k_render_tile, dim3(grid_blocks), dim3(VRC_RENDER_BLOCK), lds, st, a);
     } else {
-        const size_t lds = 2 * (size_t)a.depth * VRC_RENDER_BLOCK * sizeof(stack_t) + 1536 + 128 + 64;   // two stacks, tables, the waves' counters, camera path
+        const size_t lds = 2 * (size_t)a.depth * VRC_RENDER_BLOCK * sizeof(stack_t) + 1536 + 128 + 64 + 32;   // two stacks, tables, the waves' counters, camera path, iterations not executed
         const bool pinhole = camera_is_pinhole(a.cam);
         const bool one = a.p.gi_bounces <= 1u, fused = a.fused_resolve != 0u;
         const uint32_t waves = a.waves;
         struct Build { void (*fn)(const FrameArgs); const char* name; };
 #define VRC_BUILD(k) Build{k, #k}
         const Build b =
-            (waves == 8u && pinhole && one)  ? (fused ? VRC_BUILD(k_render_sync_pinhole_resolved_w8) : VRC_BUILD(k_render_sync_pinhole_w8)) :
-            (waves == 8u && pinhole)         ? (fused ? VRC_BUILD(k_render_sync_pinhole2_resolved_w8) : VRC_BUILD(k_render_sync_pinhole2_w8)) :
-            (waves == 7u && pinhole && one)  ? (fused ? VRC_BUILD(k_render_sync_pinhole_resolved_w7) : VRC_BUILD(k_render_sync_pinhole_w7)) :
-            (waves == 7u && one)             ? (fused ? VRC_BUILD(k_render_sync_resolved_w7) : VRC_BUILD(k_render_sync_w7)) :
+            (waves == 7u && !pinhole && one) ? (fused ? VRC_BUILD(k_render_sync_resolved_w7) : VRC_BUILD(k_render_sync_w7)) :
             pinhole ? (one ? (fused ? VRC_BUILD(k_render_sync_pinhole_resolved) : VRC_BUILD(k_render_sync_pinhole))
                            : (fused ? VRC_BUILD(k_render_sync_pinhole2_resolved) : VRC_BUILD(k_render_sync_pinhole2)))
                     : (one ? (fused ? VRC_BUILD(k_render_sync_resolved) : VRC_BUILD(k_render_sync))

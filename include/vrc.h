@@ -182,6 +182,9 @@ typedef struct vrc_frame_stats {
     uint64_t sum_complexity;  /* sum of HitPoint::complexity over them (8 B each = algorithmic bytes) */
     uint64_t primary_hits;
     uint64_t pixels;          /* pixel-samples shaded */
+    uint64_t iterations_not_executed;  /* the part of sum_complexity the frame kernels counted without executing: a ray next to
+                                        * the previous hit (or the camera) starts below the root, at the end of the descends
+                                        * that lsvo.hpp:72-111 would make from the root (same walk, same count) */
 } vrc_frame_stats;
 
 /* Streams for hosts that do not link the HIP runtime themselves: every `void *stream` argument of

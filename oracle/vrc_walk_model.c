@@ -25,8 +25,10 @@
  *      - s0 >= scale of the previous hit (those parents are on the stack),
  *      - no multiple of 2^s0 ulps lies within 8 ulps of an origin coordinate (the centre planes the skipped comparisons
  *        test; their rounding error is below 4.5 ulps of the coordinate),
- *      - LOD test (:82) cannot fire in a cell that holds the origin when coef <= 0.5, bias = 0 and |d| = 1 (caller's
- *        promise: tc_max <= sqrt(3) * scale_f there).
+ *      - the LOD test (:82) cannot fire in a cell that holds the origin: tc_max <= scale_f / max|d_i| there, so with bias 0
+ *        it needs coef < max|d_i| -- the frame kernels cast with coef 0.5 (or 0) and check max|d_i| > 0.55, which every
+ *        unit vector satisfies (>= 0.577) and a direction that collapsed to (+-EPS, +-EPS, +-EPS) does not (the light at
+ *        1e30: normalize() returns 0, :44-46 make it EPS, and the reference's first iteration is an LOD hit).
  *    Otherwise the ray starts at the root as in the reference.
  */
 #include <math.h>
@@ -86,7 +88,12 @@ void orc_model_cast(const orc_lnode *raw, uint32_t depth, const float org[3], co
     uint32_t rows[24];
     memset(rows, 0, sizeof(rows));
 
-    if (prev && prev->valid) {
+    int may_start_below = prev && prev->valid;
+#ifndef ORC_MODEL_NO_DIRECTION_GUARD   /* (tests of the test: without the guard the model must differ from the oracle) */
+    if (coef != 0.0f || bias != 0.0f)
+        may_start_below = may_start_below && bias == 0.0f && coef <= 0.5f && smax(fabsf(dx), smax(fabsf(dy), fabsf(dz))) > 0.55f;
+#endif
+    if (may_start_below) {
         const uint32_t ob[3] = { f2u(px), f2u(py), f2u(pz) };
         const uint32_t hb[3] = { f2u(prev_pos[0]), f2u(prev_pos[1]), f2u(prev_pos[2]) };
         uint32_t db = 0u, mb = 0u;

@@ -116,7 +116,7 @@ def test_round3_bench_line_contract(name):
 
 def test_round3_headline_line():
     d = load3("final_bench.json.log")
-    assert d["steps"] == 100 and d["config"]["frames_in_flight"] == 3 and d["roofline"]["kernel"] == "k_render_sync_pinhole_resolved_w8"
+    assert d["steps"] == 100 and d["config"]["frames_in_flight"] == 3 and d["roofline"]["kernel"] == "k_render_sync_pinhole_resolved"
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "Mrays/s" and c["cores"] >= 1
     one = d["extra"]["one_frame_in_flight"]

@@ -30,7 +30,7 @@ def test_struct_sizes(built):
     from cpuvoxelraycaster_amd import capi
     assert C.sizeof(capi.Camera) == 15 * 4
     assert C.sizeof(capi.FrameParams) == 14 * 4
-    assert C.sizeof(capi.FrameStats) == 32
+    assert C.sizeof(capi.FrameStats) == 40
     assert capi.HIT_DTYPE.itemsize == 48 and capi.LNODE_DTYPE.itemsize == 8
 
 

@@ -1,4 +1,4 @@
-"""The stage-synchronous frame kernel exists in builds for 6, 7 and 8 waves per SIMD (vrc_internal.h: sync_waves_for).
+"""The stage-synchronous frame kernel exists in builds for 6 waves per SIMD and, the lens kernel, 7 (vrc_internal.h: sync_waves_for).
 Every build renders the same frame bit for bit -- against the oracle on a small frame with the build forced through
 vrc_renderer_set_tuning(blocks_per_cu), and build against build at BASELINE size where the library picks by the kind of
 launch; vrc_renderer_last_kernel names what ran."""
@@ -56,9 +56,9 @@ def test_forced_builds_equal_the_oracle(scene, textures, aperture):
             assert (st.rays, st.sum_complexity) == (rays, steps), (blocks, fused)
             names.add(rc.lastKernel())
     base = "k_render_sync_pinhole" if aperture == 0.0 else "k_render_sync"
-    want = {base, base + "_resolved", base + "_w7", base + "_resolved_w7"}
-    if aperture == 0.0:
-        want |= {base + "_w8", base + "_resolved_w8"}
+    want = {base, base + "_resolved"}
+    if aperture != 0.0:
+        want |= {base + "_w7", base + "_resolved_w7"}
     assert names == want
 
 
@@ -70,14 +70,14 @@ def test_library_choice_at_baseline_size(textures):
     pin = vrc.reference_camera(depth, pitch=-0.5)
     dof = vrc.reference_camera(depth, pitch=-0.5, aperture=0.5, focal_length=60.0)
     cases = [  # camera, whole-spp units, GI, spp, bounces, expected kernel
-        (pin, False, True, spp, 1, "k_render_sync_pinhole_w7"),
-        (pin, True, True, spp, 1, "k_render_sync_pinhole_w8"),
-        (pin, True, False, spp, 1, "k_render_sync_pinhole_w8"),
+        (pin, False, True, spp, 1, "k_render_sync_pinhole"),
+        (pin, True, True, spp, 1, "k_render_sync_pinhole"),
+        (pin, True, False, spp, 1, "k_render_sync_pinhole"),
         (pin, False, False, 1, 1, "k_render_sync_pinhole"),
         (dof, False, True, spp, 1, "k_render_sync"),
         (dof, True, True, spp, 1, "k_render_sync_w7"),
         (dof, False, False, spp, 1, "k_render_sync"),
-        (pin, True, True, spp, 2, "k_render_sync_pinhole2_w8"),
+        (pin, True, True, spp, 2, "k_render_sync_pinhole2"),
         (pin, False, True, spp, 2, "k_render_sync_pinhole2"),
         (dof, True, True, spp, 2, "k_render_sync2"),
     ]

@@ -43,9 +43,12 @@ def model_cast(L, nodes, depth, org, dir_, coef, prev=None, prev_pos=None, threa
 
 
 def normalize(v):
+    """glm::normalize: v * (1 / sqrt(dot(v, v))) in float32 (overflow to inf -> 0 * v, as in the reference)"""
     v = v.astype(np.float32)
-    n = np.sqrt((v * v).sum(axis=1, dtype=np.float32)).astype(np.float32)
-    return (v / n[:, None]).astype(np.float32)
+    with np.errstate(over="ignore", invalid="ignore", divide="ignore"):
+        n = (v[:, 0] * v[:, 0] + v[:, 1] * v[:, 1] + v[:, 2] * v[:, 2]).astype(np.float32)
+        inv = (np.float32(1.0) / np.sqrt(n).astype(np.float32)).astype(np.float32)
+        return (v * inv[:, None]).astype(np.float32)
 
 
 def same(a, b):
@@ -106,6 +109,19 @@ def camera_rays(n, depth, rng, pitch):
     inv = f(1.0) / f(1 << depth)
     o = (np.asarray(cam.position, f) * inv + f(1.0)).astype(f)
     return np.broadcast_to(o, (n, 3)).copy(), normalize(d)
+
+
+def test_model_equals_oracle_with_the_light_anywhere():
+    """the light inside the cube, on a voxel boundary, and so far away that normalize() of the direction to it returns 0 (then
+    lsvo.hpp:44-46 make the direction (+-EPS, +-EPS, +-EPS) and a ray cast with an LOD coefficient ends in its first iteration)"""
+    import cpuvoxelraycaster_amd as vrc
+    L = model_lib()
+    depth = 7
+    nodes = vrc.build_terrain_lsvo(O.load_terrain_heights(), depth)
+    rng = np.random.default_rng(11)
+    for light in ([1.31, 1.62, 1.4], [1.5, 1.75, 1.25], [3e29, -8e29, 1e30], [1e19, 1e19, -1e19], [-40.0, 900.0, 12.0]):
+        org, dir_ = camera_rays(60000, depth, rng, -0.7)
+        chains(nodes, depth, org, dir_, np.asarray(light, np.float32), rng, L)
 
 
 @pytest.mark.parametrize("depth,n", [(7, 120000), (9, 250000)])
