@@ -119,3 +119,31 @@ def test_arbitrary_geometry(built, textures, seed):
                               fov=float(rng.uniform(0.5, 1.5)), aperture=float(rng.choice([0.0, 0.3])), focal_length=float(rng.uniform(1, 60)))
         light = vrc.reference_light(depth) if k else rng.uniform(1.0, 2.0, 3).astype(np.float32)
         frame_pair(vrc, svo, nodes, textures, depth, 90, 52, cam, light, spp=2, gi_bounces=1 + k % 2)
+
+
+@pytest.mark.parametrize("depth", [2, 3, 4, 10, 11])
+def test_shallow_and_deep_trees(built, textures, depth):
+    """the stack copies move rows in groups of three and the camera path in groups from the top: depths that are no multiple of
+    three, trees shallower than one group, and the deepest trees the library accepts (two stacks of 11 rows)"""
+    import cpuvoxelraycaster_amd as vrc
+    rng = np.random.default_rng(depth)
+    if depth <= 4:
+        S0 = 1 << depth
+        vol = (rng.random((S0, S0, S0)) < 0.3).astype(np.uint8)
+        vol[:, S0 // 2:, :] |= (rng.random((S0, S0 - S0 // 2, S0)) < 0.5).astype(np.uint8)
+        svo = vrc.LSVO.fromVolume(vol, depth, textures=textures)
+    elif depth <= 10:
+        svo = vrc.LSVO.fromFastNoiseTerrain(depth, textures=textures)
+    else:                                         # 2048^3: a patch of ground and scattered voxels through the oracle's builder
+        S0 = 1 << depth
+        xz = np.stack(np.meshgrid(np.arange(900, 1150), np.arange(900, 1150), indexing="ij"), -1).reshape(-1, 2)
+        ground = np.stack([xz[:, 0], np.full(len(xz), 1100) + (xz[:, 0] // 16 + xz[:, 1] // 8) % 7, xz[:, 1]], axis=1)
+        vox = np.concatenate([ground, rng.integers(0, S0, (30000, 3))]).astype(np.int64)
+        svo = vrc.LSVO(O.compile_voxels(depth, vox), depth, textures=textures)
+    nodes = svo.downloadNodes()
+    S = float(1 << depth)
+    for k in range(2):
+        pos = (S / 2 + rng.uniform(-S / 9, S / 9), S / 2 - rng.uniform(0.44, 0.48) * S, S / 2 + rng.uniform(-S / 9, S / 9))
+        cam = vrc.make_camera(pos, vrc.make_rotation(float(rng.uniform(-3, 3)), float(rng.uniform(-1.2, -0.3))),
+                              fov=float(rng.uniform(0.6, 1.3)), aperture=0.0 if k == 0 else 0.3, focal_length=float(rng.uniform(5, 60)))
+        frame_pair(vrc, svo, nodes, textures, depth, 72, 40, cam, vrc.reference_light(depth), spp=2, gi_bounces=1 + k)
