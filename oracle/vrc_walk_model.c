@@ -112,6 +112,7 @@ void orc_model_cast(const orc_lnode *raw, uint32_t depth, const float org[3], co
             parent = rows[s0];
             complexity = 22u - (uint32_t)s0;
             *skipped = complexity;
+            t_min = 0.0f;      /* as the kernel sets it (ray_setup_below): the entry into the cube lies behind such an origin */
         }
     }
 
