@@ -336,9 +336,10 @@ int vrc_set_kernel(uint32_t kernel);
  * units are accumulated with integer atomics (same sums).  Values >= 0xffff0000 set the
  * automatic mode's tail policy instead: low 16 bits = units per wave with the halved chunk. */
 int vrc_set_sample_chunk(uint32_t samples_per_unit);
-/* The stage-synchronous kernel exists in builds for 6, 7 and 8 resident workgroups per CU (= waves per
- * SIMD); the library picks one by the kind of launch (csrc/vrc_internal.h: sync_waves_for), and
- * blocks_per_cu = 6, 7 or 8 picks it for the caller (fewer: the 6-wave build on fewer workgroups).
+/* The stage-synchronous kernel is built for 6 resident workgroups per CU (= waves per SIMD) and, for
+ * cameras with a lens, also for 7; the library picks by the kind of launch (csrc/vrc_internal.h:
+ * sync_waves_for), and blocks_per_cu >= 7 picks the 7-wave build where there is one (fewer than 6:
+ * the 6-wave build on fewer workgroups).
  * vrc_renderer_last_kernel: the symbol of the frame kernel the renderer's last frame launched
  * (what a profile of the run lists), "" before the first frame. */
 const char *vrc_renderer_last_kernel(const vrc_renderer *r);
