@@ -55,10 +55,62 @@ static inline float gsign(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f 
 static inline float frac_(float x) { return x - floorf(x); }
 static inline int highbit(uint32_t x) { return x ? 31 - __builtin_clz(x) : -1; }
 
-/* One ray.  prev / prev_pos: state and hit position of the ray this one starts next to (NULL: start at the root).
+/* The paths from the root to the cell around a camera position (vrc_device.h: camera_path), one per combination of ray
+ * direction signs: variant bit i = the ray travels towards +axis i.  That only matters for an axis on which the position is
+ * EXACTLY 1.5, the centre plane of the cube -- the reference's default camera sits at size / 2 on x and z (main.cpp:100-102).
+ * There the first child choice (:66-68) is `1.5 * t_coef - t_offset > t_min` with t_offset = fl(1.5 * t_coef) (mirrored:
+ * fl(3 t_coef) - fl(1.5 t_coef) = 2 fl(1.5 t_coef) - fl(1.5 t_coef), the same number): exactly 0 > 0, false -- in the walk's
+ * mirrored frame every such ray takes the half BELOW 1.5, the half it travels into, and from there on its origin is the
+ * upper face of its cell at every level: the centre planes are half a cell away (robust), the exits through the lower
+ * corner too.  So such an axis takes no margin test; its coordinate counts as 1.5 - 1 ulp in the mirrored frame, i.e. the
+ * cells just below 1.5 for a ray towards -axis and just above for a ray towards +axis. */
+typedef struct orc_camera_paths {
+    uint32_t rows[8][24];
+    uint32_t scale[8];      /* the scale a camera ray of that variant starts at (22: at the root) */
+    uint32_t onplane;       /* axes whose coordinate is exactly 1.5 */
+} orc_camera_paths;
+
+void orc_model_camera_paths(const orc_lnode *raw, uint32_t depth, const float cam[3], orc_camera_paths *out)
+{
+    memset(out, 0, sizeof(*out));
+    uint32_t a[3] = { f2u(cam[0]), f2u(cam[1]), f2u(cam[2]) };
+    for (int i = 0; i < 3; i++) if (cam[i] == 1.5f) out->onplane |= 1u << i;
+    uint32_t mb = 0u;
+    int inside = 1;
+    for (int i = 0; i < 3; i++) {
+        if (!((out->onplane >> i) & 1u)) mb |= (a[i] - ORC_MARGIN) ^ (a[i] + ORC_MARGIN);
+        inside = inside && (a[i] >> 23) == 127u;
+    }
+    const int depth_off = 23 - (int)depth;
+    int lowest = highbit(mb + mb);
+    if (lowest < depth_off) lowest = depth_off;
+    if (lowest < 23 - 3 * ((int)depth / 3)) lowest = 23 - 3 * ((int)depth / 3);    /* the kernel copies rows in groups of three */
+    for (uint32_t v = 0; v < 8u; v++) {
+        uint32_t b[3];
+        for (int i = 0; i < 3; i++) b[i] = (((out->onplane >> i) & 1u) && !((v >> i) & 1u)) ? a[i] - 1u : a[i];
+        int s = 22;
+        uint32_t parent = 0u;
+        if (inside) {
+            while (s > lowest) {
+                const orc_lnode nd = raw[parent];
+                const uint32_t cs = 7u ^ (((b[0] >> s) & 1u) | (((b[1] >> s) & 1u) << 1) | (((b[2] >> s) & 1u) << 2));
+                if (!((nd.child_mask >> cs) & 1u) || ((nd.leaf_mask >> cs) & 1u)) break;
+                out->rows[v][s] = parent;
+                parent += nd.child_offset + cs;
+                --s;
+            }
+        }
+        out->rows[v][s] = parent;
+        out->scale[v] = (uint32_t)s;
+    }
+}
+
+/* One ray.  prev / prev_pos: state and hit position of the ray this one starts next to (NULL: start at the root); or cam: the
+ * ray starts AT the camera position these paths were made for (org == that position).
  * *skipped = iterations not executed (already part of out->complexity). */
-void orc_model_cast(const orc_lnode *raw, uint32_t depth, const float org[3], const float dir[3], float coef, float bias,
-                    const orc_walk_state *prev, const float prev_pos[3], orc_hit *out, orc_walk_state *st, uint32_t *skipped)
+static void model_cast(const orc_lnode *raw, uint32_t depth, const float org[3], const float dir[3], float coef, float bias,
+                       const orc_walk_state *prev, const float prev_pos[3], const orc_camera_paths *cam,
+                       orc_hit *out, orc_walk_state *st, uint32_t *skipped)
 {
     memset(out, 0, sizeof(*out));
     memset(st, 0, sizeof(*st));
@@ -88,7 +140,25 @@ void orc_model_cast(const orc_lnode *raw, uint32_t depth, const float org[3], co
     uint32_t rows[24];
     memset(rows, 0, sizeof(rows));
 
-    int may_start_below = prev && prev->valid;
+    if (cam) {
+        const uint32_t v = mirror ^ 7u;
+        const int s0 = (int)cam->scale[v];
+        if (s0 < 22) {
+            float m[3] = { (mirror & 1u) ? px : 3.0f - px, (mirror & 2u) ? py : 3.0f - py, (mirror & 4u) ? pz : 3.0f - pz };
+            for (int i = 0; i < 3; i++) if ((cam->onplane >> i) & 1u) m[i] = u2f(f2u(1.5f) - 1u);
+            const uint32_t keep = 0xffffffffu << s0;
+            posx = u2f(f2u(m[0]) & keep); posy = u2f(f2u(m[1]) & keep); posz = u2f(f2u(m[2]) & keep);
+            co = ((f2u(m[0]) >> s0) & 1u) | (((f2u(m[1]) >> s0) & 1u) << 1) | (((f2u(m[2]) >> s0) & 1u) << 2);
+            scale = (uint32_t)s0;
+            sf = u2f((uint32_t)(s0 - SVO_MAX + 127) << 23);
+            memcpy(rows, cam->rows[v], sizeof(rows));
+            parent = rows[s0];
+            complexity = 22u - (uint32_t)s0;
+            *skipped = complexity;
+            t_min = 0.0f;
+        }
+    }
+    int may_start_below = !cam && prev && prev->valid;
 #ifndef ORC_MODEL_NO_DIRECTION_GUARD   /* (tests of the test: without the guard the model must differ from the oracle) */
     if (coef != 0.0f || bias != 0.0f)
         may_start_below = may_start_below && bias == 0.0f && coef <= 0.5f && smax(fabsf(dx), smax(fabsf(dy), fabsf(dz))) > 0.55f;
@@ -189,6 +259,25 @@ void orc_model_cast(const orc_lnode *raw, uint32_t depth, const float org[3], co
         st->scale = scale;
         st->valid = 1u;
     }
+}
+
+void orc_model_cast(const orc_lnode *raw, uint32_t depth, const float org[3], const float dir[3], float coef, float bias,
+                    const orc_walk_state *prev, const float prev_pos[3], orc_hit *out, orc_walk_state *st, uint32_t *skipped)
+{
+    model_cast(raw, depth, org, dir, coef, bias, prev, prev_pos, 0, out, st, skipped);
+}
+
+/* n camera rays from one position (a pinhole camera's primary rays, main.cpp:149) */
+void orc_model_cast_camera_rays(const orc_lnode *raw, uint32_t depth, uint64_t n, const float cam[3], const float *dir,
+                                orc_hit *out, orc_walk_state *st, uint32_t *skipped, uint32_t *scales, int threads)
+{
+    orc_camera_paths paths;
+    orc_model_camera_paths(raw, depth, cam, &paths);
+    if (scales) memcpy(scales, paths.scale, sizeof(paths.scale));
+    if (threads < 1) threads = 1;
+#pragma omp parallel for schedule(dynamic, 1024) num_threads(threads)
+    for (int64_t i = 0; i < (int64_t)n; i++)
+        model_cast(raw, depth, cam, dir + 3 * i, 0.0f, 0.0f, 0, 0, &paths, out + i, st + i, skipped + i);
 }
 
 /* n independent chains: ray i starts next to hit i of the previous call (prev / prev_pos NULL: from the root) */
