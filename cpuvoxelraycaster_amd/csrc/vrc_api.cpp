@@ -615,7 +615,7 @@ int render_impl(vrc_renderer* r, const vrc_camera* cam, const vrc_frame_params* 
         if (bpc > fit) bpc = fit;
         if (bpc > vrc::tile_max_blocks_per_cu()) bpc = vrc::tile_max_blocks_per_cu();
     } else if (tuning.kernel == VRC_KERNEL_SYNC) {
-        const uint32_t lds = 2u * s->depth * 1024u + 1536u + 128u + 64u;  // two stacks (primary path, secondary walks), tables, counters, camera path
+        const uint32_t lds = 2u * s->depth * 1024u + 1536u + 128u + 544u + 32u;  // two stacks (primary path, secondary walks), tables, counters, camera paths
         const uint32_t fit = 163840u / lds;
         // which build of the kernel (waves per SIMD = workgroups per CU): by the kind of launch, or the caller's choice
         const bool whole_spp = a.p.use_samples && a.p.spp > 1 && tuning.sample_chunk >= a.p.spp;

@@ -113,6 +113,9 @@ __device__ __forceinline__ float get_rand(uint32_t k, float mn, float mx)
 
 constexpr int SVO_MAX = 23;  // lsvo.hpp:37
 typedef uint32_t stack_t;    // one stack entry: a parent index (see ray_step); a walk needs `depth` rows of them
+// camera paths in the frame kernels' LDS (camera_path): 8 variants x 16 entries (rows by scale, entry 15 = the path's scale), then
+// one entry with the lowest of those scales and 7 of padding
+constexpr uint32_t VRC_CAMERA_PATH_BYTES = 8u * 16u * 4u + 32u;
 // Safety net (same constant as the oracle): no finite ray needs anywhere near
 // this many loop iterations; guarantees the kernels terminate.
 constexpr uint32_t MAX_ITERATIONS = 65536u;
@@ -315,9 +318,9 @@ __device__ __forceinline__ void ray_run(Ray& r, bool active, const uint2* __rest
 // wave's LDS counters -- ctr[0] += loop iterations of all lanes, ctr[1] += lanes that cast a ray -- and leaves
 // r.complexity alone.  One no-return LDS add pair by the first lane that ran; no per-lane counter stays live.
 // The stage-synchronous kernels keep, per wave, {iterations executed, rays, primary hits, pixel-samples} in four consecutive
-// u64 (16 of them for the workgroup's four waves), the camera path (64 B) after those, and then the waves' counts of
+// u64 (16 of them for the workgroup's four waves), the camera paths (VRC_CAMERA_PATH_BYTES) after those, and then the waves' counts of
 // iterations NOT executed (rays that start below the root): ctr[VRC_CTR_NOT_EXECUTED] from a wave's own ctr.
-#define VRC_CTR_NOT_EXECUTED ((16u * 8u + 64u) / 8u - 3u * (threadIdx.x >> 6))
+#define VRC_CTR_NOT_EXECUTED ((16u * 8u + VRC_CAMERA_PATH_BYTES) / 8u - 3u * (threadIdx.x >> 6))
 __device__ __forceinline__ void book_walk(unsigned long long* ctr, uint32_t wave_steps)
 {
     // every lane that makes the call casts a ray (one that ray_setup rejected is a ray of complexity 0, as in the oracle)
@@ -416,12 +419,27 @@ __device__ __forceinline__ void copy_stack(stack_t* dst, const stack_t* src, int
 // mirrored frame inverts them once more) must exist and be no leaf, and the point must keep the margin of
 // start_scale_next_to from the planes of the next scale.  path[scale - depth_off] = parent at that scale, for the scales from
 // the returned one up to 22; a camera ray then starts like a ray next to a hit at the camera position with that scale.
-__device__ __forceinline__ uint32_t camera_path(const uint2* __restrict__ nodes, int depth, float cx, float cy, float cz, stack_t* path)
+//
+// A coordinate that is EXACTLY 1.5, the centre plane of the cube -- the reference's default camera sits at size / 2 on x and z
+// (main.cpp:100-102) -- fails that margin at every scale, but needs none: there the first child choice (:66-68) is
+// `1.5 * t_coef - t_offset > t_min` with t_offset = fl(1.5 * t_coef) (a mirrored axis: fl(3 t_coef) - fl(1.5 t_coef) =
+// 2 fl(1.5 t_coef) - fl(1.5 t_coef), the same number): exactly 0 > 0, false.  In the walk's mirrored frame every ray takes the
+// half BELOW 1.5, the half it travels into, and from there on the origin is the upper face of its cell at every level: the
+// centre planes are half a cell away, the exits (lower corners) a whole one.  So with `centre_planes` such an axis is left out
+// of the margin test and its coordinate counts as 1.5 - 1 ulp in the mirrored frame: the cells just below 1.5 for a ray towards
+// -axis, just above for a ray towards +axis -- one path per `variant` (bit i: towards +axis i), 8 of them.
+// (oracle/vrc_walk_model.c: orc_model_camera_paths; tests/test_walk_model.py::test_camera_rays_start_on_the_camera_path.)
+__device__ __forceinline__ uint32_t camera_path(const uint2* __restrict__ nodes, int depth, float cx, float cy, float cz,
+                                                bool centre_planes, uint32_t variant, stack_t* path)
 {
-    const uint32_t a = f2u(cx), b = f2u(cy), c = f2u(cz);
-    const uint32_t mb = ((a - 8u) ^ (a + 8u)) | ((b - 8u) ^ (b + 8u)) | ((c - 8u) ^ (c + 8u));
+    uint32_t a = f2u(cx), b = f2u(cy), c = f2u(cz);
+    const bool px = centre_planes && cx == 1.5f, py = centre_planes && cy == 1.5f, pz = centre_planes && cz == 1.5f;
+    const uint32_t mb = (px ? 0u : (a - 8u) ^ (a + 8u)) | (py ? 0u : (b - 8u) ^ (b + 8u)) | (pz ? 0u : (c - 8u) ^ (c + 8u));
     // all three in [1, 2): sign 0, exponent 127 (the margin test covers the ends of the interval)
     const bool inside = ((a >> 23) == 127u) && ((b >> 23) == 127u) && ((c >> 23) == 127u);
+    if (px && !(variant & 1u)) a -= 1u;
+    if (py && !(variant & 2u)) b -= 1u;
+    if (pz && !(variant & 4u)) c -= 1u;
     const int depth_off = SVO_MAX - depth;
     // (copy_camera_path moves the rows in groups of three from the top: no deeper than the groups that fit the column)
     const int lowest = max(max(31 - __clz((int)(mb + mb)), depth_off), SVO_MAX - 3 * (depth / 3));
@@ -442,14 +460,14 @@ __device__ __forceinline__ uint32_t camera_path(const uint2* __restrict__ nodes,
     return (uint32_t)s;
 }
 
-// the rows of a camera path from its scale up, into a lane's stack column (before every camera ray: walks overwrite them);
-// in groups of three from the top row -- what a group carries below the path's scale is never read
+// the rows of a camera path into a lane's stack column (before every camera ray: walks overwrite them), in groups of three
+// from the top row down to `lowest_scale` (what a group carries below a path's own scale is never read)
 template <int STRIDE>
-__device__ __forceinline__ void copy_camera_path(stack_t* dst, const stack_t* path, int depth, uint32_t cam_scale)
+__device__ __forceinline__ void copy_camera_path(stack_t* dst, const stack_t* path, int depth, uint32_t lowest_scale)
 {
     dst += (depth - 3) * STRIDE; path += depth - 3;
 #pragma unroll 1
-    for (int g = cam_scale < 22u ? (SVO_MAX - (int)cam_scale + 2) / 3 : 0; g > 0; --g) {     // a path that ends at the root: nothing to copy
+    for (int g = lowest_scale < 22u ? (SVO_MAX - (int)lowest_scale + 2) / 3 : 0; g > 0; --g) {     // paths that end at the root: nothing to copy
         const stack_t a = path[0], b = path[1], c = path[2];
         dst[0] = a; dst[STRIDE] = b; dst[2 * STRIDE] = c;
         dst -= 3 * STRIDE; path -= 3;
@@ -467,6 +485,21 @@ __device__ __forceinline__ void ray_start_below(Ray& r, uint32_t s0, float ox, f
         r.py = (r.mirror & 2u) ? oy : 3.0f - oy;
         r.pz = (r.mirror & 4u) ? oz : 3.0f - oz;
         r.scale = (int)s0;
+    }
+#endif
+}
+
+// ray_start_below for a camera ray (origin = the camera position): an axis on the cube's centre plane (camera_path) counts as
+// 1.5 - 1 ulp in the mirrored frame, whichever way the ray goes
+__device__ __forceinline__ void ray_start_at_camera(Ray& r, uint32_t s0, float ox, float oy, float oz)
+{
+    ray_start_below(r, s0, ox, oy, oz);
+#if !(defined(VRC_WALK_CPP) || defined(VRC_PROBE) || defined(VRC_NO_START_BELOW))
+    if (s0 < 22u) {
+        const float below = u2f(f2u(1.5f) - 1u);
+        if (ox == 1.5f) r.px = below;
+        if (oy == 1.5f) r.py = below;
+        if (oz == 1.5f) r.pz = below;
     }
 #endif
 }

@@ -1039,7 +1039,7 @@ __device__ __forceinline__ uint32_t albedo_of(const uint8_t* tex, const Hit& h)
 template <bool PINHOLE, bool ONE_BOUNCE, bool FUSED>
 __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
 {
-    // [depth][2][256] two stacks, their rows interleaved | 1536 B textures | 4 waves x 4 counters | camera path (16 entries) |
+    // [depth][2][256] two stacks, their rows interleaved | 1536 B textures | 4 waves x 4 counters | camera paths (8 x 16 entries + 8) |
     // 4 waves' count of iterations not executed
     extern __shared__ stack_t lds_dyn[];
     stack_t* stk = lds_dyn + threadIdx.x;                              // the path to the primary hit, kept until the next primary walk
@@ -1055,15 +1055,23 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
     if (lane == 4u) ctr[VRC_CTR_NOT_EXECUTED] = 0ull;
     const uint2* __restrict__ nodes = a.nodes;
     const int depth = (int)a.depth;
-    // the path from the root to the camera's cell (vrc_device.h, camera_path): camera rays start at its end
+    // the paths from the root to the camera's cell (vrc_device.h, camera_path): camera rays start at their ends.  One per
+    // combination of direction signs (they differ only for a pinhole camera on the cube's centre planes -- the reference's
+    // default pose; with a lens the lens point decides, and a camera on a centre plane starts its rays at the root)
     stack_t* const cam_path = reinterpret_cast<stack_t*>(tex + 1536 + 128);
-    if (threadIdx.x == 0u) {
+    if (threadIdx.x < 8u) {
         const float isz = 1.0f / (float)(1u << a.depth);
-        cam_path[15] = camera_path(nodes, depth, (a.cam.position[0] + 0.0f) * isz + 1.0f, (a.cam.position[1] + 0.0f) * isz + 1.0f,
-                                   (a.cam.position[2] + 0.0f) * isz + 1.0f, cam_path);
+        cam_path[threadIdx.x * 16u + 15u] = camera_path(nodes, depth, (a.cam.position[0] + 0.0f) * isz + 1.0f, (a.cam.position[1] + 0.0f) * isz + 1.0f,
+                                                        (a.cam.position[2] + 0.0f) * isz + 1.0f, PINHOLE, threadIdx.x, cam_path + threadIdx.x * 16u);
     }
     __syncthreads();
-    const uint32_t cam_scale = __builtin_amdgcn_readfirstlane(cam_path[15]);
+    if (threadIdx.x == 0u) {
+        uint32_t lowest = 22u;
+        for (uint32_t v = 0; v < 8u; ++v) lowest = min(lowest, cam_path[v * 16u + 15u]);
+        cam_path[128] = lowest;
+    }
+    __syncthreads();
+    const uint32_t cam_scale = __builtin_amdgcn_readfirstlane(cam_path[128]);     // the lowest scale a camera ray starts at
 
     const uint2 root = nodes[0];
     const uint32_t W = a.width, H = a.height;
@@ -1195,11 +1203,13 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
                 float oz = (a.cam.position[2] + 0.0f) * inv_size + 1.0f;
                 Ray r0, r;
                 bool active = ray_setup(r0, root, ox, oy, oz, dx, dy, dz);
-                ray_start_below(r0, cam_scale, ox, oy, oz);                         // every camera ray starts at the camera
+                // every camera ray starts at the camera, on the path of its direction signs
+                const stack_t* const my_cam_path = cam_path + (r0.mirror ^ 7u) * 16u;
+                ray_start_at_camera(r0, cam_scale < 22u ? my_cam_path[15] : 22u, ox, oy, oz);
                 r = r0;
                 for (uint32_t k = 0; k < n_walks; ++k) {                            // raycaster.hpp:131, once per sample
                     r = r0;
-                    copy_camera_path<VRC_SYNC_ROW>(stk, cam_path, depth, cam_scale);
+                    copy_camera_path<VRC_SYNC_ROW>(stk, my_cam_path, depth, cam_scale);
                     if (a.prim) {                                                   // the capture records the ray's own complexity
                         const uint32_t not_executed = book_not_executed(ctr, active, r);
                         ray_run<VRC_SYNC_ROW, 0, true>(r, active, nodes, stk, depth, 0.0f, 0.0f);
@@ -1686,7 +1696,7 @@ hipError_t launch_render(const FrameArgs& a, uint32_t grid_blocks, int kernel, h
         const size_t lds = (size_t)a.depth * VRC_RENDER_BLOCK * sizeof(stack_t) + 4 * TILE_WAVE_LDS + 1536;
         hipLaunchKernelGGL(k_render_tile, dim3(grid_blocks), dim3(VRC_RENDER_BLOCK), lds, st, a);
     } else {
-        const size_t lds = 2 * (size_t)a.depth * VRC_RENDER_BLOCK * sizeof(stack_t) + 1536 + 128 + 64 + 32;   // two stacks, tables, the waves' counters, camera path, iterations not executed
+        const size_t lds = 2 * (size_t)a.depth * VRC_RENDER_BLOCK * sizeof(stack_t) + 1536 + 128 + VRC_CAMERA_PATH_BYTES + 32;   // two stacks, tables, the waves' counters, camera paths, iterations not executed
         const bool pinhole = camera_is_pinhole(a.cam);
         const bool one = a.p.gi_bounces <= 1u, fused = a.fused_resolve != 0u;
         const uint32_t waves = a.waves;

@@ -688,7 +688,7 @@ typedef struct {
     uint32_t trace_n;
     uint8_t *ops;              /* analysis hook: this pixel's per-iteration op codes, ORC_TRACE_RAYS x ops_len bytes */
     uint32_t ops_len;
-    float *geo;                /* analysis hook: this pixel's rays as {origin[3], hit position[3], hit scale, hit kind}, ORC_TRACE_RAYS x 8 floats */
+    float *geo;                /* analysis hook: this pixel's rays as {origin[3], hit position[3], hit scale, hit kind + 16 * direction signs}, ORC_TRACE_RAYS x 8 floats */
 } shade_ctx;
 
 static void ctx_cast(shade_ctx *c, v3 o, v3 d, float coef, float bias, orc_hit *out)
@@ -703,7 +703,8 @@ static void ctx_cast(shade_ctx *c, v3 o, v3 d, float coef, float bias, orc_hit *
         float *g = c->geo + (size_t)c->trace_n * 8;
         g[0] = o.x; g[1] = o.y; g[2] = o.z;
         g[3] = out->position[0]; g[4] = out->position[1]; g[5] = out->position[2];
-        g[6] = (float)((out->hit >> 16) & 0xffu); g[7] = (float)(out->hit & 0xffu);
+        g[6] = (float)((out->hit >> 16) & 0xffu);
+        g[7] = (float)((out->hit & 0xffu) + 16u * ((d.x > 0.0f ? 1u : 0u) | (d.y > 0.0f ? 2u : 0u) | (d.z > 0.0f ? 4u : 0u)));
     }
     if (c->trace && c->trace_n < ORC_TRACE_RAYS)
         c->trace[c->trace_n++] = (uint16_t)(out->complexity < 65535u ? out->complexity : 65535u);
@@ -955,7 +956,8 @@ void orc_render_frame_optrace(const orc_lnode *nodes, uint32_t depth,
     free(image); free(accum);
 }
 
-/* ... plus, per pixel and ray, {origin[3], hit position[3], hit scale, hit kind} into geo[(pixel * ORC_TRACE_RAYS + ray) * 8]:
+/* ... plus, per pixel and ray, {origin[3], hit position[3], hit scale, hit kind + 16 * (bit i: the ray goes towards +axis i)}
+ * into geo[(pixel * ORC_TRACE_RAYS + ray) * 8]:
  * what tests/tools/path_schedule.py needs to tell where the kernel starts each ray (below the root, next to the previous hit). */
 void orc_render_frame_optrace_geo(const orc_lnode *nodes, uint32_t depth,
                                   const uint8_t tex_top[768], const uint8_t tex_side[768],

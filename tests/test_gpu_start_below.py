@@ -147,3 +147,24 @@ def test_shallow_and_deep_trees(built, textures, depth):
         cam = vrc.make_camera(pos, vrc.make_rotation(float(rng.uniform(-3, 3)), float(rng.uniform(-1.2, -0.3))),
                               fov=float(rng.uniform(0.6, 1.3)), aperture=0.0 if k == 0 else 0.3, focal_length=float(rng.uniform(5, 60)))
         frame_pair(vrc, svo, nodes, textures, depth, 72, 40, cam, vrc.reference_light(depth), spp=2, gi_bounces=1 + k)
+
+
+@pytest.mark.parametrize("depth", [7, 9])
+def test_reference_pose_starts_below_the_root(built, heights, textures, depth):
+    """the reference's camera sits on the cube's centre planes x = z = 1.5: lsvo.hpp:66-68 compares fl(1.5 t_coef) with itself
+    there and every ray takes the half it travels into, so its camera rays start on a path of their own direction signs"""
+    import cpuvoxelraycaster_amd as vrc
+    import path_schedule as ps
+    nodes = vrc.build_terrain_lsvo(heights, depth)
+    svo = vrc.LSVO(nodes, depth, textures=textures)
+    f = np.float32
+    for pitch in (-0.5, 0.0, -1.2):
+        cam = vrc.reference_camera(depth, pitch=pitch)
+        cam_pos = (np.asarray(cam.position, f) * (f(1.0) / f(1 << depth)) + f(1.0)).astype(f)
+        assert (cam_pos[0], cam_pos[2]) == (1.5, 1.5)
+        scales = [ps.camera_path_scale(nodes, depth, cam_pos, v) for v in range(8)]
+        assert max(scales) < 22 and ps.camera_path_scale(nodes, depth, cam_pos, 0, centre_planes=False) == 22
+        W, H = 128, 72
+        st = frame_pair(vrc, svo, nodes, textures, depth, W, H, cam, vrc.reference_light(depth), spp=1, use_gi=0)
+        assert st.iterations_not_executed >= W * H * (22 - max(scales))
+        frame_pair(vrc, svo, nodes, textures, depth, W, H, cam, vrc.reference_light(depth), spp=2, use_gi=1, capture=False, fused=True)

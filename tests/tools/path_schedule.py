@@ -41,13 +41,20 @@ def start_scale_next_to(o, h, hit_scale):
     return np.maximum(highbit((db | (mb + mb)) & m32), np.asarray(hit_scale, np.int64))
 
 
-def camera_path_scale(nodes, depth, cam):
-    """numpy restatement of camera_path: the scale at which camera rays start (22 = at the root)"""
-    a = np.asarray(cam, np.float32).view(np.uint32).astype(np.uint64)
+def camera_path_scale(nodes, depth, cam, variant=0, centre_planes=True):
+    """numpy restatement of camera_path: the scale at which camera rays start (22 = at the root); variant bit i = the ray goes
+    towards +axis i, which matters for a coordinate exactly on the cube's centre plane 1.5 (vrc_device.h: camera_path)"""
+    cam = np.asarray(cam, np.float32)
+    a = cam.view(np.uint32).astype(np.uint64)
+    on = [bool(centre_planes and float(c) == 1.5) for c in cam]
     m32 = np.uint64(0xffffffff)
-    mb = int(np.bitwise_or.reduce(((a - np.uint64(8)) & m32) ^ ((a + np.uint64(8)) & m32)))
+    mb = 0
+    for i in range(3):
+        if not on[i]:
+            mb |= int(((a[i] - np.uint64(8)) & m32) ^ ((a[i] + np.uint64(8)) & m32))
     if not all((int(v) >> 23) == 127 for v in a):
         return 22
+    a = np.array([int(a[i]) - (1 if on[i] and not (variant >> i) & 1 else 0) for i in range(3)], np.uint64)
     lowest = max(int(highbit(np.array([(mb + mb) & 0xffffffff]))[0]), 23 - depth, 23 - 3 * (depth // 3))
     raw = nodes.view(np.uint32).reshape(-1, 2)
     s, parent = 22, 0
@@ -142,11 +149,13 @@ def main():
     # on the camera cell's path, shadow and GI rays next to the primary hit, GI shadow rays next to the GI hit
     f = np.float32
     cam_pos = (np.asarray(cam.position, f) * (f(1.0) / f(1 << depth)) + f(1.0)).astype(f)
-    cam_scale = camera_path_scale(nodes, depth, cam_pos)
-    org, hpos, hscale, hkind = geo[..., 0:3], geo[..., 3:6], geo[..., 6].astype(np.int64), geo[..., 7]
+    cam_scales = np.array([camera_path_scale(nodes, depth, cam_pos, v) for v in range(8)], np.int64)
+    cam_scale = int(cam_scales.min())
+    org, hpos, hscale = geo[..., 0:3], geo[..., 3:6], geo[..., 6].astype(np.int64)
+    hkind, signs = geo[..., 7].astype(np.int64) % 16, geo[..., 7].astype(np.int64) // 16
     skip = np.zeros((Hh, W, 8), np.int64)
-    s0 = start_scale_next_to(org[:, :, 0], np.broadcast_to(cam_pos, org[:, :, 0].shape), cam_scale)
-    skip[:, :, 0] = np.where(s0 < 22, 22 - s0, 0) if cam_scale < 22 else 0
+    # pinhole camera: every camera ray starts at the camera, on the path of its direction signs
+    skip[:, :, 0] = np.where(trace[:, :, 0] > 0, 22 - cam_scales[signs[:, :, 0]], 0)
     for ray, prev in ((1, 0), (2, 0), (3, 2)):
         s0 = start_scale_next_to(org[:, :, ray], hpos[:, :, prev], hscale[:, :, prev])
         skip[:, :, ray] = np.where((s0 < 22) & (hkind[:, :, prev] != 0) & (trace[:, :, ray] > 0), 22 - s0, 0)
