@@ -340,6 +340,7 @@ public:
         return slot;
     }
     uint64_t submitted() const { return n_; }
+    uint32_t nextSlot() const { return (uint32_t)(n_ % slots_.size()); }     // the slot (and stream) the next submit() uses
     void wait(uint32_t slot) { check(vrc_stream_synchronize(device_, streams_[slot]), "vrc_stream_synchronize"); }
     void waitAll() { for (uint32_t i = 0; i < slots_.size(); ++i) wait(i); }
     std::vector<uint8_t> image(uint32_t slot) { return slots_[slot]->render_image(streams_[slot]); }   // waits for that slot

@@ -89,10 +89,14 @@ int main(int argc, char** argv)
             HIPCHECK(hipMalloc(&full[s], (uint64_t)W * H * 4));
         }
         const bool composes = !to_root || rank == 0;
+        // a buffer set is used again S frames later, by a frame on ANOTHER stream: that frame waits for the set's last user
+        std::vector<hipEvent_t> used(S);
+        for (uint32_t s = 0; s < S; ++s) HIPCHECK(hipEventCreateWithFlags(&used[s], hipEventDisableTiming));
 
         const auto t0 = std::chrono::steady_clock::now();
         for (uint32_t i = 0; i < frames; ++i) {
             const uint32_t b = i % S;
+            if (i >= S) HIPCHECK(hipStreamWaitEvent((hipStream_t)pipe.stream(pipe.nextSlot()), used[b], 0));
             const uint32_t slot = pipe.submit(cam, mine[b]);            // frame i: this rank's rows, resolved and packed
             hipStream_t st = (hipStream_t)pipe.stream(slot);
             if (!to_root) {
@@ -110,6 +114,7 @@ int main(int argc, char** argv)
             }
             if (composes)
                 vrc_host::check(vrc_unpack_shards(gathered[b], W, H, ROW_BLOCK, (uint32_t)world, full[b], st), "vrc_unpack_shards");
+            HIPCHECK(hipEventRecord(used[b], st));
         }
         pipe.waitAll();
         HIPCHECK(hipDeviceSynchronize());
@@ -131,7 +136,7 @@ int main(int argc, char** argv)
                 if (got != want) { equal = 0; std::printf("frame %u differs from the unsharded render\n", i); }
             }
         }
-        for (uint32_t s = 0; s < S; ++s) { (void)hipFree(mine[s]); (void)hipFree(gathered[s]); (void)hipFree(full[s]); }
+        for (uint32_t s = 0; s < S; ++s) { (void)hipFree(mine[s]); (void)hipFree(gathered[s]); (void)hipFree(full[s]); (void)hipEventDestroy(used[s]); }
         if (rank == 0)
             std::printf("{\"host\": \"c++\", \"exchange\": \"%s\", \"world\": %d, \"frames\": %u, \"frames_in_flight\": %u, \"size\": [%u, %u], "
                         "\"spp\": %u, \"ms_per_frame\": %.4f, \"gathered_frames_equal_unsharded\": %s}\n",
