@@ -656,6 +656,39 @@ def main():
                     "(oracle/vrc_oracle.c global_illumination, level 1); same frame, same frames in flight and unit policy as the timed "
                     "region, measured right after it"}
 
+    if rank == 0 and world == 1 and not dist_on and not args.no_extras and args.kernel == 2 and cfg["aperture"] == 0.0 and cfg.get("gi_bounces", 1) <= 1:
+        # untimed extra, the other way round: the same frames with every ray started at the root as the reference's loop does
+        # (vrc_renderer_set_walk_from_root) instead of below it, next to the previous hit / the camera -- what the start below
+        # the root is worth; same image, same rays, same sum of complexities
+        rcs4 = [make_renderer() for _ in range(F)]
+        for r4 in rcs4:
+            r4.setWalkFromRoot(True)
+        n4 = max(10, min(args.steps, 50))
+
+        def frames4(i0, n):
+            for i in range(i0, i0 + n):
+                r4, ts4 = rcs4[i % F], tstreams[i % F]
+                r4.frame_index = i * spp
+                if fused:
+                    r4.renderFrameResolved(cam, spp=spp, stream=ts4.cuda_stream)
+                else:
+                    r4.renderFrame(cam, spp=spp, stream=ts4.cuda_stream)
+                    r4.resolveShard(reset=True, stream=ts4.cuda_stream)
+        frames4(0, 2 * F)
+        torch.cuda.synchronize()
+        for r4 in rcs4:
+            r4.stats(reset=True, stream=tstreams[0].cuda_stream)
+        t4 = time.perf_counter()
+        frames4(2 * F, n4)
+        torch.cuda.synchronize()
+        dt4 = time.perf_counter() - t4
+        sts4 = [r4.stats(stream=tstreams[0].cuda_stream) for r4 in rcs4]
+        extras["every_ray_from_the_root"] = {
+            "ms_per_step": round(dt4 / n4 * 1e3, 4), "value": round(sum(x.rays for x in sts4) / dt4 / 1e6, 2), "unit": "Mrays/s", "steps": n4,
+            "loop_iterations_not_executed": int(sum(x.iterations_not_executed for x in sts4)),
+            "note": "measurement switch (vrc_renderer_set_walk_from_root): no ray starts below the root; same image, rays and "
+                    "complexity sums as the timed region, same frames in flight and unit policy, measured right after it"}
+
     if rank == 0 and world == 1 and not dist_on and not args.no_extras and cfg["aperture"] == 0.0 and args.kernel == 2:
         # untimed extra, beyond the reference: the same frames with vrc_renderer_set_invariant_ray_reuse -- a pinhole camera's
         # primary ray and the shadow ray of its hit are the same for every sample, the reference (and `value`) walk them

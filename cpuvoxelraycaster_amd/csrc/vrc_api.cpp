@@ -56,6 +56,7 @@ struct Tuning {
     uint32_t sample_chunk = 0;   // 0 = automatic
     uint32_t tail_units_per_wave = 4;   // automatic chunking: units of half the chunk for the last tiles (0 = off); tools/chunk_time.py
     bool reuse_invariant = false;       // pinhole camera: walk a unit's sample-invariant rays once (never a process default)
+    bool walk_from_root = false;        // measurement switch: no ray starts below the root
 };
 Tuning g_tuning;
 std::mutex g_tuning_mu;
@@ -192,6 +193,13 @@ extern "C" int vrc_renderer_set_invariant_ray_reuse(vrc_renderer* r, uint32_t on
     if (!r) return fail(VRC_ERR_INVALID, "null renderer");
     if (on > 1) return fail(VRC_ERR_INVALID, "vrc_renderer_set_invariant_ray_reuse: on = %u (0 or 1)", on);
     r->tuning.reuse_invariant = on != 0;
+    return VRC_OK;
+}
+extern "C" int vrc_renderer_set_walk_from_root(vrc_renderer* r, uint32_t on)
+{
+    if (!r) return fail(VRC_ERR_INVALID, "null renderer");
+    if (on > 1) return fail(VRC_ERR_INVALID, "vrc_renderer_set_walk_from_root: on = %u (0 or 1)", on);
+    r->tuning.walk_from_root = on != 0;
     return VRC_OK;
 }
 extern "C" const char* vrc_renderer_last_kernel(const vrc_renderer* r) { return r ? r->last_kernel : ""; }
@@ -603,6 +611,7 @@ int render_impl(vrc_renderer* r, const vrc_camera* cam, const vrc_frame_params* 
     }
     a.fused_resolve = fused ? 1u : 0u;
     a.reuse_invariant = tuning.reuse_invariant ? 1u : 0u;
+    a.walk_from_root = tuning.walk_from_root ? 1u : 0u;
     a.tile_done = r->d_tile_done;
     a.resolve_dst = (uint32_t*)dst;
     uint64_t want = (items + VRC_RENDER_BLOCK - 1) / VRC_RENDER_BLOCK;

@@ -69,6 +69,8 @@ struct FrameArgs {
     // pinhole kernels (vrc_renderer_set_invariant_ray_reuse): walk a work unit's sample-invariant rays (the primary ray
     // and the shadow ray of its hit) once instead of once per sample; same image, fewer walks executed and counted
     uint32_t reuse_invariant;
+    // host only, measurement switch (vrc_renderer_set_walk_from_root): launch the pinhole one-bounce kernel's from-root build
+    uint32_t walk_from_root;
     // host only: which build of the stage-synchronous kernel to launch, by waves per SIMD (6, 7 or 8; see sync_waves_for)
     uint32_t waves;
     uint32_t* tile_done;

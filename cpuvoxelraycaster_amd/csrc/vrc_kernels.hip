@@ -851,7 +851,7 @@ __device__ __forceinline__ uint32_t probe_wave_max(uint32_t v)
 // VRC_RENDER_BLOCK entries further): the GI ray starts below the root on a copy of that path, the GI shadow ray on what the
 // GI walk left (vrc_device.h, ray_start_below).
 template <bool ONE_BOUNCE>   // true: gi_bounces == 1 is known (the reference's semantics), the chain is straight-line code
-__device__ __forceinline__ float gi_chain(const uint2* __restrict__ nodes, stack_t* const stk_hit, const uint32_t base_scale,
+__device__ __forceinline__ float gi_chain(const uint2* __restrict__ nodes, stack_t* const stk_hit, const uint32_t base_scale, const bool from_root,
                                           const uint2 root, const int depth,
                                           const float n_normalizer, const float lx, const float ly, const float lz,
                                           const uint32_t gi_bounces_rt, const uint32_t seed, const uint32_t fr, const uint32_t pix,
@@ -885,8 +885,8 @@ __device__ __forceinline__ float gi_chain(const uint2* __restrict__ nodes, stack
         if (level == 0u) dgi[0] = dot_gi; else dgi[1] = dot_gi;
         active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
         if (level == 0u) {     // (a deeper level starts at the root: the GI shadow walk has used the stack since its hit)
-            copy_stack<VRC_SYNC_ROW>(stk, stk_hit, depth);
-            ray_start_below(r, start_scale_next_to_lod(ox, oy, oz, base_px, base_py, base_pz, base_scale, dx, dy, dz), ox, oy, oz);
+            if (!from_root) copy_stack<VRC_SYNC_ROW>(stk, stk_hit, depth);
+            ray_start_below(r, (from_root ? 22u : start_scale_next_to_lod(ox, oy, oz, base_px, base_py, base_pz, base_scale, dx, dy, dz)), ox, oy, oz);
         }
         ray_run_total_below<VRC_SYNC_ROW, 1>(r, active, nodes, stk, depth, 0.5f, 0.0f, ctr);   // :194
         Hit g;
@@ -901,7 +901,7 @@ __device__ __forceinline__ float gi_chain(const uint2* __restrict__ nodes, stack
             const float dotl = dot3(g.nx, g.ny, g.nz, dx, dy, dz);         // :200
             const float contrib = 1000000.0f * smin(0.5f, smax(0.0f, dotl) * dot_gi);   // :201
             active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
-            ray_start_below(r, start_scale_next_to_lod(ox, oy, oz, g.px, g.py, g.pz, (g.hit >> 16) & 0xffu, dx, dy, dz), ox, oy, oz);
+            ray_start_below(r, (from_root ? 22u : start_scale_next_to_lod(ox, oy, oz, g.px, g.py, g.pz, (g.hit >> 16) & 0xffu, dx, dy, dz)), ox, oy, oz);
             ray_run_total_below<VRC_SYNC_ROW, 1>(r, active, nodes, stk, depth, 0.5f, 0.0f, ctr);   // :198
             if (!r.kind) { if (level == 0u) acc[0] += contrib; else acc[1] += contrib; }
             if (level + 1u < gi_bounces) {
@@ -922,7 +922,7 @@ __device__ __forceinline__ float gi_chain(const uint2* __restrict__ nodes, stack
 // rejects gi_bounces > 2, launch_render sends gi_bounces <= 1 to the one-bounce kernels).  Same operations in the same
 // order as gi_chain<false> with gi_bounces = 2 -- level 0 from the primary hit with draws 2, 3, level 1 from the GI hit with
 // draws 4, 5, gi = max(0, acc0 + dot_gi0 * max(0, acc1)) -- without the loop-carried level / draw / base state.
-__device__ __forceinline__ float gi_two_levels(const uint2* __restrict__ nodes, stack_t* const stk_hit, const uint32_t base_scale,
+__device__ __forceinline__ float gi_two_levels(const uint2* __restrict__ nodes, stack_t* const stk_hit, const uint32_t base_scale, const bool from_root,
                                                const uint2 root, const int depth,
                                                const float n_normalizer, const float lx, const float ly, const float lz,
                                                const uint32_t seed, const uint32_t fr, const uint32_t pix,
@@ -950,8 +950,8 @@ __device__ __forceinline__ float gi_two_levels(const uint2* __restrict__ nodes, 
         normalize3(dx, dy, dz);
         dgi0 = dot3(dx, dy, dz, b0nx, b0ny, b0nz);                        // :193
         active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
-        copy_stack<VRC_SYNC_ROW>(stk, stk_hit, depth);
-        ray_start_below(r, start_scale_next_to_lod(ox, oy, oz, b0px, b0py, b0pz, base_scale, dx, dy, dz), ox, oy, oz);
+        if (!from_root) copy_stack<VRC_SYNC_ROW>(stk, stk_hit, depth);
+        ray_start_below(r, (from_root ? 22u : start_scale_next_to_lod(ox, oy, oz, b0px, b0py, b0pz, base_scale, dx, dy, dz)), ox, oy, oz);
         ray_run_total_below<VRC_SYNC_ROW, 1>(r, active, nodes, stk, depth, 0.5f, 0.0f, ctr);   // :194
     }
     Hit g;
@@ -965,7 +965,7 @@ __device__ __forceinline__ float gi_two_levels(const uint2* __restrict__ nodes, 
         const float dotl = dot3(g.nx, g.ny, g.nz, dx, dy, dz);             // :200
         const float contrib = 1000000.0f * smin(0.5f, smax(0.0f, dotl) * dgi0);   // :201
         active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
-        ray_start_below(r, start_scale_next_to_lod(ox, oy, oz, g.px, g.py, g.pz, (g.hit >> 16) & 0xffu, dx, dy, dz), ox, oy, oz);
+        ray_start_below(r, (from_root ? 22u : start_scale_next_to_lod(ox, oy, oz, g.px, g.py, g.pz, (g.hit >> 16) & 0xffu, dx, dy, dz)), ox, oy, oz);
         ray_run_total_below<VRC_SYNC_ROW, 1>(r, active, nodes, stk, depth, 0.5f, 0.0f, ctr);   // :198
         if (!r.kind) acc0 += contrib;
         // ---- level 1: the same from the GI hit
@@ -997,7 +997,7 @@ __device__ __forceinline__ float gi_two_levels(const uint2* __restrict__ nodes, 
             const float dotl1 = dot3(g1.nx, g1.ny, g1.nz, dx, dy, dz);
             const float contrib1 = 1000000.0f * smin(0.5f, smax(0.0f, dotl1) * dgi1);
             active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
-            ray_start_below(r, start_scale_next_to_lod(ox, oy, oz, g1.px, g1.py, g1.pz, (g1.hit >> 16) & 0xffu, dx, dy, dz), ox, oy, oz);
+            ray_start_below(r, (from_root ? 22u : start_scale_next_to_lod(ox, oy, oz, g1.px, g1.py, g1.pz, (g1.hit >> 16) & 0xffu, dx, dy, dz)), ox, oy, oz);
             ray_run_total_below<VRC_SYNC_ROW, 1>(r, active, nodes, stk, depth, 0.5f, 0.0f, ctr);
             if (!r.kind) acc1 += contrib1;
         }
@@ -1036,7 +1036,7 @@ __device__ __forceinline__ uint32_t albedo_of(const uint8_t* tex, const Hit& h)
 // Then a pixel's camera ray is the same for every sample, and so are its primary hit, albedo and shadow ray(s): a work
 // unit sets them up ONCE and walks them once per sample of the unit (every ray the reference casts is still walked and
 // counted; only the identical arithmetic around the walks is not repeated).  The per-sample work is the GI pair.
-template <bool PINHOLE, bool ONE_BOUNCE, bool FUSED>
+template <bool PINHOLE, bool ONE_BOUNCE, bool FUSED, bool FROM_ROOT = false>
 __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
 {
     // [depth][2][256] two stacks, their rows interleaved | 1536 B textures | 4 waves x 4 counters | camera paths (8 x 16 entries + 8) |
@@ -1071,7 +1071,10 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
         cam_path[128] = lowest;
     }
     __syncthreads();
-    const uint32_t cam_scale = __builtin_amdgcn_readfirstlane(cam_path[128]);     // the lowest scale a camera ray starts at
+    // (FROM_ROOT: the builds behind vrc_renderer_set_walk_from_root, a measurement switch: no ray starts below the root.  A
+    // kernel argument instead costs every frame 1 %: one more live SGPR and a select per ray)
+    constexpr bool from_root = FROM_ROOT;
+    const uint32_t cam_scale = from_root ? 22u : __builtin_amdgcn_readfirstlane(cam_path[128]);     // the lowest scale a camera ray starts at
 
     const uint2 root = nodes[0];
     const uint32_t W = a.width, H = a.height;
@@ -1240,10 +1243,10 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
                     normalize3(dx, dy, dz);
                     const float lit = smax(0.0f, dot3(dx, dy, dz, h.nx, h.ny, h.nz));           // :156
                     active = ray_setup(r0, root, ox, oy, oz, dx, dy, dz);
-                    ray_start_below(r0, start_scale_next_to(ox, oy, oz, h.px, h.py, h.pz, h.hit >> 16), ox, oy, oz);
+                    ray_start_below(r0, from_root ? 22u : start_scale_next_to(ox, oy, oz, h.px, h.py, h.pz, h.hit >> 16), ox, oy, oz);
                     for (uint32_t k = n_shadow_walks; k--;) {
                         r = r0;
-                        copy_stack<VRC_SYNC_ROW>(stk + VRC_RENDER_BLOCK, stk, depth);
+                        if (!from_root) copy_stack<VRC_SYNC_ROW>(stk + VRC_RENDER_BLOCK, stk, depth);
                         ray_run_total_below<VRC_SYNC_ROW, 0>(r, active, nodes, stk + VRC_RENDER_BLOCK, depth, 0.0f, 0.0f, ctr);
                     }
                     if (!r.kind) light_intensity = lit;                                      // :155-157
@@ -1257,10 +1260,10 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
                         float gi_intensity = 0.0f;
                         if (a.p.use_gi) {
                             if constexpr (ONE_BOUNCE)
-                                gi_intensity = gi_chain<ONE_BOUNCE>(nodes, stk, albedo >> 24, root, depth, n_normalizer, lx, ly, lz, gi_bounces, a.p.seed,
+                                gi_intensity = gi_chain<ONE_BOUNCE>(nodes, stk, albedo >> 24, from_root, root, depth, n_normalizer, lx, ly, lz, gi_bounces, a.p.seed,
                                                     a.p.frame_index + sample, pix, hpx, hpy, hpz, hnx, hny, hnz, ctr);
                             else
-                                gi_intensity = gi_two_levels(nodes, stk, albedo >> 24, root, depth, n_normalizer, lx, ly, lz, a.p.seed,
+                                gi_intensity = gi_two_levels(nodes, stk, albedo >> 24, from_root, root, depth, n_normalizer, lx, ly, lz, a.p.seed,
                                                     a.p.frame_index + sample, pix, hpx, hpy, hpz, hnx, hny, hnz, ctr);
                         }
                         color = color_mult(albedo, smin(1.0f, smax(0.0f, light_intensity + gi_intensity)));   // :163
@@ -1347,8 +1350,8 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
                             normalize3(dx, dy, dz);
                             const float lit = smax(0.0f, dot3(dx, dy, dz, h.nx, h.ny, h.nz));       // :156
                             active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
-                            copy_stack<VRC_SYNC_ROW>(stk + VRC_RENDER_BLOCK, stk, depth);
-                            ray_start_below(r, start_scale_next_to(ox, oy, oz, h.px, h.py, h.pz, (h.hit >> 16) & 0xffu), ox, oy, oz);
+                            if (!from_root) copy_stack<VRC_SYNC_ROW>(stk + VRC_RENDER_BLOCK, stk, depth);
+                            ray_start_below(r, from_root ? 22u : start_scale_next_to(ox, oy, oz, h.px, h.py, h.pz, (h.hit >> 16) & 0xffu), ox, oy, oz);
                             ray_run_total_below<VRC_SYNC_ROW, 0>(r, active, nodes, stk + VRC_RENDER_BLOCK, depth, 0.0f, 0.0f, ctr);
                             VRC_PROBE_WALK(r, 1)
                             if (!r.kind) light_intensity = lit;                                  // :155-157
@@ -1357,10 +1360,10 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
                         float gi_intensity = 0.0f;
                         if (a.p.use_gi) {
                             if constexpr (ONE_BOUNCE)
-                                gi_intensity = gi_chain<ONE_BOUNCE>(nodes, stk, (h.hit >> 16) & 0xffu, root, depth, n_normalizer, lx, ly, lz, gi_bounces, a.p.seed, fr, pix,
+                                gi_intensity = gi_chain<ONE_BOUNCE>(nodes, stk, (h.hit >> 16) & 0xffu, from_root, root, depth, n_normalizer, lx, ly, lz, gi_bounces, a.p.seed, fr, pix,
                                                     h.px, h.py, h.pz, h.nx, h.ny, h.nz, ctr);
                             else
-                                gi_intensity = gi_two_levels(nodes, stk, (h.hit >> 16) & 0xffu, root, depth, n_normalizer, lx, ly, lz, a.p.seed, fr, pix,
+                                gi_intensity = gi_two_levels(nodes, stk, (h.hit >> 16) & 0xffu, from_root, root, depth, n_normalizer, lx, ly, lz, a.p.seed, fr, pix,
                                                     h.px, h.py, h.pz, h.nx, h.ny, h.nz, ctr);
                         }
                         color = color_mult(albedo, smin(1.0f, smax(0.0f, light_intensity + gi_intensity)));   // :163
@@ -1484,6 +1487,16 @@ VRC_SYNC_KERNEL(k_render_sync_pinhole2_resolved, true, false, true, VRC_SYNC_MIN
 VRC_SYNC_KERNEL(k_render_sync_w7, false, true, false, 7)
 VRC_SYNC_KERNEL(k_render_sync_resolved_w7, false, true, true, 7)
 #undef VRC_SYNC_KERNEL
+// the pinhole one-bounce kernels with every ray started at the root, as lsvo.hpp:60-72 does (vrc_renderer_set_walk_from_root: a
+// measurement switch -- bench.py's extra.every_ray_from_the_root says what the start below the root is worth)
+extern "C" __global__ void __launch_bounds__(VRC_RENDER_BLOCK, VRC_SYNC_MIN_WAVES) k_render_sync_pinhole_from_root(const FrameArgs a)
+{
+    render_sync_body<true, true, false, true>(a);
+}
+extern "C" __global__ void __launch_bounds__(VRC_RENDER_BLOCK, VRC_SYNC_MIN_WAVES) k_render_sync_pinhole_resolved_from_root(const FrameArgs a)
+{
+    render_sync_body<true, true, true, true>(a);
+}
 
 // ---------------------------------------------------------------------------
 // S4 sink + plumbing
@@ -1704,6 +1717,7 @@ hipError_t launch_render(const FrameArgs& a, uint32_t grid_blocks, int kernel, h
 #define VRC_BUILD(k) Build{k, #k}
         const Build b =
             (waves == 7u && !pinhole && one) ? (fused ? VRC_BUILD(k_render_sync_resolved_w7) : VRC_BUILD(k_render_sync_w7)) :
+            (a.walk_from_root && pinhole && one) ? (fused ? VRC_BUILD(k_render_sync_pinhole_resolved_from_root) : VRC_BUILD(k_render_sync_pinhole_from_root)) :
             pinhole ? (one ? (fused ? VRC_BUILD(k_render_sync_pinhole_resolved) : VRC_BUILD(k_render_sync_pinhole))
                            : (fused ? VRC_BUILD(k_render_sync_pinhole2_resolved) : VRC_BUILD(k_render_sync_pinhole2)))
                     : (one ? (fused ? VRC_BUILD(k_render_sync_resolved) : VRC_BUILD(k_render_sync))

@@ -234,6 +234,7 @@ public:
     void setSampleChunk(uint32_t samples_per_unit) { check(vrc_renderer_set_sample_chunk(r_, samples_per_unit), "vrc_renderer_set_sample_chunk"); }
     // ... and, beyond the reference, the sample-invariant primary / shadow walks of a pinhole camera done once per unit
     void setInvariantRayReuse(bool on) { check(vrc_renderer_set_invariant_ray_reuse(r_, on ? 1u : 0u), "vrc_renderer_set_invariant_ray_reuse"); }
+    void setWalkFromRoot(bool on) { check(vrc_renderer_set_walk_from_root(r_, on ? 1u : 0u), "vrc_renderer_set_walk_from_root"); }
 
     void samples_to_image(void* stream = nullptr) { check(vrc_samples_to_image(r_, stream), "vrc_samples_to_image"); }   // raycaster.hpp:94
     void resetSamples(void* stream = nullptr) { check(vrc_reset_samples(r_, stream), "vrc_reset_samples"); }            // raycaster.hpp:105

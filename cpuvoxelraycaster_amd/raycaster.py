@@ -212,6 +212,10 @@ class RayCaster:
         """symbol of the frame kernel the last renderFrame* launched (what a rocprofv3 trace of the run lists)"""
         return capi.load().vrc_renderer_last_kernel(self._h).decode()
 
+    def setWalkFromRoot(self, on=True):
+        """Measurement switch: every ray from the root (none starts below it).  include/vrc.h: vrc_renderer_set_walk_from_root."""
+        check(capi.load().vrc_renderer_set_walk_from_root(self._h, 1 if on else 0))
+
     def setInvariantRayReuse(self, on=True):
         """beyond the reference: pinhole camera, walk a work unit's primary and shadow ray once instead of once per sample
         (same image; stats then count the walks executed).  include/vrc.h: vrc_renderer_set_invariant_ray_reuse."""

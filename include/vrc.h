@@ -355,6 +355,13 @@ int vrc_renderer_set_sample_chunk(vrc_renderer *r, uint32_t samples_per_unit);
  * for bit the same; vrc_frame_stats.rays / sum_complexity then count the walks EXECUTED, i.e.
  * fewer than the reference's.  No effect with aperture != 0 or on the A/B kernels 0 and 1. */
 int vrc_renderer_set_invariant_ray_reuse(vrc_renderer *r, uint32_t on);
+/* Measurement switch (off by default): on = 1 makes the stage-synchronous kernel start EVERY ray at
+ * the root, as lsvo.hpp:60-72 does, instead of below it next to the previous hit / the camera
+ *  -- for frames of a pinhole camera (aperture +0) with one GI bounce, the
+ * reference's configuration, which have a build for it; other frames ignore it.  Same image, same
+ * vrc_frame_stats.rays / sum_complexity either way; iterations_not_executed is 0 with it.  (bench.py
+ * reports the frame time with it as extra.every_ray_from_the_root.) */
+int vrc_renderer_set_walk_from_root(vrc_renderer *r, uint32_t on);
 
 #ifdef __cplusplus
 }

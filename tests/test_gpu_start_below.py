@@ -168,3 +168,28 @@ def test_reference_pose_starts_below_the_root(built, heights, textures, depth):
         st = frame_pair(vrc, svo, nodes, textures, depth, W, H, cam, vrc.reference_light(depth), spp=1, use_gi=0)
         assert st.iterations_not_executed >= W * H * (22 - max(scales))
         frame_pair(vrc, svo, nodes, textures, depth, W, H, cam, vrc.reference_light(depth), spp=2, use_gi=1, capture=False, fused=True)
+
+
+def test_walk_from_root_switch(terrain7, textures):
+    """vrc_renderer_set_walk_from_root: every ray from the root -- the same accumulators and counters, no iteration left out"""
+    import cpuvoxelraycaster_amd as vrc
+    nodes, svo = terrain7
+    L = vrc.capi.load()
+    W, H, spp = 120, 68, 3
+    for aperture in (0.0,):                        # (frames with a lens or two bounces have no such build and ignore the switch)
+        cam = vrc.make_camera((61.7, 9.3, 70.2), vrc.make_rotation(0.4, -0.6), fov=1.0, aperture=aperture, focal_length=40.0)
+        out = []
+        for on in (False, True):
+            rc = vrc.RayCaster(svo, (W, H))
+            rc.setLightPosition(vrc.reference_light(7))
+            rc.use_gi, rc.use_samples, rc.shadow_samples = True, True, 1
+            rc.setWalkFromRoot(on)
+            rc.renderFrame(cam, spp=spp)
+            out.append((rc.readAccum(), rc.stats()))
+            assert rc.lastKernel() == ("k_render_sync_pinhole_from_root" if on else "k_render_sync_pinhole")
+        (a0, s0), (a1, s1) = out
+        assert np.array_equal(a0, a1)
+        assert (s0.rays, s0.sum_complexity, s0.primary_hits, s0.pixels) == (s1.rays, s1.sum_complexity, s1.primary_hits, s1.pixels)
+        assert s0.iterations_not_executed > 0.1 * s0.sum_complexity and s1.iterations_not_executed == 0
+    rc = vrc.RayCaster(svo, (8, 8))
+    assert L.vrc_renderer_set_walk_from_root(rc._h, 2) == -1 and L.vrc_renderer_set_walk_from_root(None, 1) == -1
