@@ -421,7 +421,7 @@ __device__ __forceinline__ void copy_stack(stack_t* dst, const stack_t* src, int
 // the returned one up to 22; a camera ray then starts like a ray next to a hit at the camera position with that scale.
 //
 // A coordinate that is EXACTLY 1.5, the centre plane of the cube -- the reference's default camera sits at size / 2 on x and z
-// (main.cpp:100-102) -- fails that margin at every scale, but needs none: there the first child choice (:66-68) is
+// (main.cpp:51: (256, 200, 256) at 512^3) -- fails that margin at every scale, but needs none: there the first child choice (:66-68) is
 // `1.5 * t_coef - t_offset > t_min` with t_offset = fl(1.5 * t_coef) (a mirrored axis: fl(3 t_coef) - fl(1.5 t_coef) =
 // 2 fl(1.5 t_coef) - fl(1.5 t_coef), the same number): exactly 0 > 0, false.  In the walk's mirrored frame every ray takes the
 // half BELOW 1.5, the half it travels into, and from there on the origin is the upper face of its cell at every level: the

@@ -57,7 +57,7 @@ static inline int highbit(uint32_t x) { return x ? 31 - __builtin_clz(x) : -1; }
 
 /* The paths from the root to the cell around a camera position (vrc_device.h: camera_path), one per combination of ray
  * direction signs: variant bit i = the ray travels towards +axis i.  That only matters for an axis on which the position is
- * EXACTLY 1.5, the centre plane of the cube -- the reference's default camera sits at size / 2 on x and z (main.cpp:100-102).
+ * EXACTLY 1.5, the centre plane of the cube -- the reference's default camera sits at size / 2 on x and z (main.cpp:51: (256, 200, 256) at 512^3).
  * There the first child choice (:66-68) is `1.5 * t_coef - t_offset > t_min` with t_offset = fl(1.5 * t_coef) (mirrored:
  * fl(3 t_coef) - fl(1.5 t_coef) = 2 fl(1.5 t_coef) - fl(1.5 t_coef), the same number): exactly 0 > 0, false -- in the walk's
  * mirrored frame every such ray takes the half BELOW 1.5, the half it travels into, and from there on its origin is the
