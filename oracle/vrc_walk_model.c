@@ -41,6 +41,8 @@
 #define ORC_MARGIN 8u     /* ulps; the comparisons of the skipped iterations are exact beyond 4.5 */
 #endif
 
+int orc_model_descend_by_position = 0;     /* study switch: see model_cast */
+
 typedef struct orc_walk_state {
     uint32_t rows[24];      /* parent index by scale (the LDS stack column of a lane) */
     uint32_t scale;         /* scale of the hit child; rows[scale] = the hit's parent */
@@ -140,6 +142,8 @@ static void model_cast(const orc_lnode *raw, uint32_t depth, const float org[3],
     uint32_t rows[24];
     memset(rows, 0, sizeof(rows));
 
+    float start_m[3] = { 0.0f, 0.0f, 0.0f };
+    uint32_t start_mb = 0xffffffffu;
     if (cam) {
         const uint32_t v = mirror ^ 7u;
         const int s0 = (int)cam->scale[v];
@@ -156,6 +160,7 @@ static void model_cast(const orc_lnode *raw, uint32_t depth, const float org[3],
             complexity = 22u - (uint32_t)s0;
             *skipped = complexity;
             t_min = 0.0f;
+            /* (a camera path already ends where the descends by position end: nothing below it) */
         }
     }
     int may_start_below = !cam && prev && prev->valid;
@@ -182,7 +187,29 @@ static void model_cast(const orc_lnode *raw, uint32_t depth, const float org[3],
             parent = rows[s0];
             complexity = 22u - (uint32_t)s0;
             *skipped = complexity;
+            start_m[0] = mx; start_m[1] = my; start_m[2] = mz; start_mb = mb;
             t_min = 0.0f;      /* as the kernel sets it (ray_setup_below): the entry into the cube lies behind such an origin */
+        }
+    }
+
+    /* ... and from there on down by position while the next iterations are descends as well: the child around the origin is
+     * present and no leaf (node data), and the origin keeps the margin from the planes of the next scale.  (The common parent
+     * of origin and hit is only where their PATHS part; the cell around the origin usually exists a level or two deeper.) */
+    if (orc_model_descend_by_position && *skipped && start_mb != 0xffffffffu) {
+        int lowest = highbit(start_mb + start_mb);
+        while ((int)scale > lowest && (int)scale > 23 - (int)depth) {
+            const orc_lnode nd = raw[parent];
+            const uint32_t cs = co ^ mirror;
+            if (!((nd.child_mask >> cs) & 1u) || ((nd.leaf_mask >> cs) & 1u)) break;
+            rows[scale] = parent;
+            parent += nd.child_offset + cs;
+            --scale;
+            sf *= 0.5f;
+            const uint32_t keep = 0xffffffffu << scale;
+            posx = u2f(f2u(start_m[0]) & keep); posy = u2f(f2u(start_m[1]) & keep); posz = u2f(f2u(start_m[2]) & keep);
+            co = ((f2u(start_m[0]) >> scale) & 1u) | (((f2u(start_m[1]) >> scale) & 1u) << 1) | (((f2u(start_m[2]) >> scale) & 1u) << 2);
+            ++complexity;
+            ++*skipped;
         }
     }
 
