@@ -29,6 +29,11 @@ and reported as `extra.one_frame_in_flight`.
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
+Both lines work for every N.  Started plainly (no WORLD_SIZE in the environment) with N > 1, this process is only the
+fork/join (the one call of main.cpp:139-154, execute + waitExecutionDone): before anything that could touch the GPU is
+imported it starts N fresh children, one rank per GPU, with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, waits for them
+and exits with the worst child's code (`launch_ranks`).  Rank 0 inherits stdout, so the JSON line stays the last line.
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -225,6 +230,80 @@ def cpu_baseline(cfg, nodes, textures, cam, light, budget_s=3.5):
             "variants": out}
 
 
+def rank_environments(n, base_env, port):
+    """The environment of each of the N ranks of one node -- what torch.distributed.run would set for them."""
+    envs = []
+    for r in range(n):
+        e = dict(base_env)
+        e.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                  "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "VRC_BENCH_LAUNCHED_BY": str(os.getpid()),
+                  "HSA_ENABLE_IPC_MODE_LEGACY": base_env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+        envs.append(e)
+    return envs
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, argv, popen=None, grace_s=20.0):
+    """`python bench.py --gpus N` without a launcher: start N children (fresh processes -- never an exec of this one), one
+    rank per GPU, and join them.  This process imports nothing that can initialise the GPU.  Rank 0 inherits stdout (its
+    JSON line is the last line of ours); the other ranks' stdout goes to our stderr.  When a rank fails, the others get
+    `grace_s` seconds to leave by themselves (a peer blocked in a collective would wait for ever) and are then ended BY
+    PID.  Returns the worst exit code."""
+    import signal
+    import subprocess
+    real = popen is None
+    if real:                                                     # (a test passes its own popen from a process that has torch loaded)
+        assert "torch" not in sys.modules, "the fork/join process must not have imported torch"
+    popen = popen or subprocess.Popen
+    port = int(os.environ.get("MASTER_PORT") or free_port())
+    envs = rank_environments(n, os.environ, port)
+    if os.environ.get("VRC_BENCH_LAUNCH_DRYRUN") == "1":         # tests/test_bench_launch.py: the plan, nothing started
+        keys = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "HSA_ENABLE_IPC_MODE_LEGACY")
+        print(json.dumps({"argv": [sys.executable, os.path.abspath(__file__)] + list(argv), "ranks": [{k: e[k] for k in keys} for e in envs],
+                          "torch_imported": "torch" in sys.modules, "modules_touching_gpu": sorted(m for m in sys.modules if m.split(".")[0] in ("torch", "cpuvoxelraycaster_amd", "ctypes"))}))
+        return 0
+    procs = []
+    for r, e in enumerate(envs):
+        procs.append(popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=e,
+                           stdout=(None if r == 0 else sys.stderr), stderr=None))
+
+    def end_all(sig=signal.SIGTERM):
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    p.send_signal(sig)                            # this child's PID, nothing by pattern
+                except OSError:
+                    pass
+
+    def on_signal(signum, _frame):
+        end_all(signal.SIGTERM)
+        sys.exit(128 + signum)
+    for sg in (signal.SIGINT, signal.SIGTERM) if real else ():
+        signal.signal(sg, on_signal)
+    first_failure = None
+    while any(p.poll() is None for p in procs):
+        bad = [p for p in procs if p.poll() not in (None, 0)]
+        if bad and first_failure is None:
+            first_failure = time.monotonic()
+            print(f"bench.py: rank {procs.index(bad[0])} exited with {bad[0].returncode}; the other ranks get {grace_s:.0f} s", file=sys.stderr, flush=True)
+        if first_failure is not None and time.monotonic() - first_failure > grace_s:
+            end_all(signal.SIGTERM)
+            time.sleep(2.0)
+            end_all(signal.SIGKILL)
+        time.sleep(0.05)
+    codes = [p.returncode for p in procs]
+    worst = max((abs(c) for c in codes), default=0)
+    if worst:
+        print(f"bench.py: rank exit codes {codes}", file=sys.stderr, flush=True)
+    return min(worst, 255)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -254,6 +333,11 @@ def main():
                     help="frame kernel: 2 stage-synchronous per tile (default), 0 tile-phased with LDS job pool, 1 persistent mixed-stage")
     args = ap.parse_args()
 
+    # the fork/join of main.cpp:139-154 across GPUs: plain `python bench.py --gpus N` starts its own ranks -- decided here,
+    # before torch (or anything else that can touch the GPU) is imported
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -266,8 +350,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
         sys.exit(f"bench.py --gpus {args.gpus} launched with WORLD_SIZE={world}: they must agree")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
@@ -282,6 +364,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
+    if world > torch.cuda.device_count() and backend == "nccl":
+        sys.exit(f"bench.py --gpus {world}: this node has {torch.cuda.device_count()} GPU(s) and RCCL needs one per rank "
+                 "(VRC_DIST_BACKEND=gloo rehearses the N > 1 path with ranks sharing a GPU)")
+    ranks_share_gpus = world > torch.cuda.device_count()
     local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if dist_on:
@@ -840,6 +926,10 @@ def main():
                        + ((", direct peer writes into rank 0's framebuffers (hipIpc), no collective" if args.gather == "peer" else
                           f", RCCL {'gather to rank 0' if args.gather == 'root' else 'all-gather'} of RGBA8 shards") if dist_on else ""),
                        "ranks_in_process_group": (dist.get_world_size() if dist_on else 1),
+                       "launched_by": ("bench.py itself (launch_ranks)" if os.environ.get("VRC_BENCH_LAUNCHED_BY") else
+                                       "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "plain"),
+                       "distinct_gpus": min(world, torch.cuda.device_count()),
+                       "exchange_backend": (backend if dist_on else None),
                        "gathered_frame_equals_unsharded": verified},
             "roofline": roof,
         }

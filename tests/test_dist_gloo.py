@@ -68,20 +68,24 @@ def _worker(rank, world, port, W, H, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_frame_over_gloo_ranks_matches_unsharded(built, heights, textures, world):
+@pytest.mark.parametrize("world,W,H", [(2, 200, 100),      # 13 row blocks: uneven split over 2 and over 3 ranks, last block partial
+                                       (3, 200, 100),
+                                       (8, 48, 1080)])     # BASELINE configs 3/4's height on 8 ranks: 135 row blocks = seven ranks own 17, rank 7 owns 16
+def test_sharded_frame_over_gloo_ranks_matches_unsharded(built, heights, textures, world, W, H):
     import oracle_lib as O
     import cpuvoxelraycaster_amd as vrc
-    W, H = 200, 100             # 13 row blocks: uneven split over 2 and over 3 ranks, last block partial
+    import cpuvoxelraycaster_amd.dist as vd
+    if world == 8:
+        assert [len(vd.owned_rows(H, vd.ROW_BLOCK, r, world)) // vd.ROW_BLOCK for r in range(8)] == [17] * 7 + [16]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, W, H, q)) for r in range(world)]
     for p in procs:
         p.start()
-    full, tot = q.get(timeout=240)
+    full, tot = q.get(timeout=480)
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
     depth = 7
     nodes = O.compile_terrain(depth, heights)

@@ -24,19 +24,21 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_peer_written_frames_equal_unsharded(built, world):
     port = _free_port()
     procs = []
+    # world 8 = the node the metric is quoted on, rehearsed on one GPU: 1080 rows = 135 row blocks, seven ranks own 17, rank 7 owns 16
+    size = dict(PW_W="1920", PW_H="1080") if world == 8 else {}
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", **size)
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "peer_write_worker.py")], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = []
     for p in procs:
         try:
-            o, e = p.communicate(timeout=40)
+            o, e = p.communicate(timeout=40 if world < 8 else 180)
         except subprocess.TimeoutExpired:
             for q in procs:
                 q.kill()
@@ -48,13 +50,13 @@ def test_peer_written_frames_equal_unsharded(built, world):
     d = json.loads(line)
     assert d["frames"] == 9 and d["frames_in_flight"] == 3 and d["world"] == world
     assert d["composed_frame_equals_unsharded"] == [True] * 9, d
-    log = os.path.join(ROOT, "gpurun_out", "r03")
+    log = os.path.join(ROOT, "gpurun_out", "r04")
     os.makedirs(log, exist_ok=True)
     with open(os.path.join(log, f"peer_write_world{world}.json.log"), "w") as f:
         f.write(line + "\n")
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_cpp_host_peer_writes(built, tmp_path, world):
     """the same exchange from a C++ host: tests/cpp/peer_write_main.cpp (vrc_host::HipFramePipeline + HipRayCaster::exportImage /
     setImageTarget + the frame flags), `world` forked processes on GPU 0"""
@@ -65,18 +67,19 @@ def test_cpp_host_peer_writes(built, tmp_path, world):
                            "-L" + libdir, "-l:libvrc_hip.so", "-L/opt/rocm/lib", "-lamdhip64", "-lpthread",
                            "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
     data = os.path.join(libdir, "data")
-    p = subprocess.Popen([exe, str(world), "8", "1280", "720", "4", "9", os.path.join(data, "grass_top_16x16.rgb"),
+    W, H = ("1920", "1080") if world == 8 else ("1280", "720")
+    p = subprocess.Popen([exe, str(world), "8", W, H, "4", "9", os.path.join(data, "grass_top_16x16.rgb"),
                           os.path.join(data, "grass_side_16x16.rgb")], env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"),
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
     try:
-        out, err = p.communicate(timeout=60)
+        out, err = p.communicate(timeout=60 if world < 8 else 180)
     except subprocess.TimeoutExpired:
         os.killpg(p.pid, 9)                                    # the forked ranks are in the program's own process group
         raise AssertionError("peer_write_main timed out")
     assert p.returncode == 0, out + err
     d = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
     assert d["composed_frames_equal_unsharded"] is True and d["world"] == world and d["frames"] == 9 and d["frames_in_flight"] == 3
-    log = os.path.join(ROOT, "gpurun_out", "r03")
+    log = os.path.join(ROOT, "gpurun_out", "r04")
     os.makedirs(log, exist_ok=True)
     with open(os.path.join(log, f"cpp_peer_write_world{world}.json.log"), "w") as f:
         f.write(json.dumps(d) + "\n")
