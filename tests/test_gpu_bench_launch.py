@@ -1,0 +1,40 @@
+"""The plain launch line for N > 1 on the GPU box (round-3 verdict, item 1): `python bench.py --gpus N` with no launcher in
+the line starts its own ranks.  One GPU here, so the ranks share it and exchange over gloo (VRC_DIST_BACKEND=gloo); the
+gathered frame must equal the unsharded one and the JSON line must be the last line of stdout."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("world,gather", [(2, "root"), (8, "peer")])
+def test_plain_bench_line_launches_its_ranks(built, world, gather):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["VRC_DIST_BACKEND"] = "gloo"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "5", "--warmup", "2", "--blocks", "1",
+                          "--blocks-min-seconds", "0", "--gather", gather, "--config", "c4"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == world and d["config"]["ranks_in_process_group"] == world
+    assert d["config"]["gathered_frame_equals_unsharded"] is True
+    assert d["config"]["launched_by"].startswith("bench.py itself") and d["config"]["distinct_gpus"] == 1
+    log = os.path.join(ROOT, "gpurun_out", "r04")
+    os.makedirs(log, exist_ok=True)
+    with open(os.path.join(log, f"self_launch_gloo{world}_{gather}.json.log"), "w") as f:
+        f.write(json.dumps(d) + "\n")
+
+
+def test_nccl_on_too_few_gpus_fails_loudly(built):
+    """RCCL needs one GPU per rank: on this one-GPU box the plain line must leave non-zero with the reason, not hang"""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("more than one GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "VRC_DIST_BACKEND")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "RCCL needs one per rank" in out.stderr
