@@ -64,6 +64,7 @@ SYMBOLS = {
     "vrc_terrain_heights": (_int, [_i32, _u32, _int, _vp]),
     "vrc_scene_build_fastnoise_terrain": (_int, [_i32, _u32, _int, C.POINTER(_vp), C.POINTER(C.c_float)]),
     "vrc_cast_rays": (_int, [_vp, _u64, _vp, _vp, _vp, _vp, _vp, _int, _vp]),
+    "vrc_cast_ray_chains": (_int, [_vp, _u64, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp]),
     "vrc_cast_ray": (_int, [_vp, _vp, _vp, _f32, _f32, _vp]),
     "vrc_grid_create": (_int, [_vp, _i32, _i32, _i32, _int, C.POINTER(_vp)]),
     "vrc_grid_destroy": (_int, [_vp]),
@@ -104,6 +105,7 @@ SYMBOLS = {
     "vrc_renderer_set_sample_chunk": (_int, [_vp, _u32]),
     "vrc_renderer_set_invariant_ray_reuse": (_int, [_vp, _u32]),
     "vrc_renderer_set_walk_from_root": (_int, [_vp, _u32]),
+    "vrc_renderer_set_lane_samples": (_int, [_vp, _u32]),
     "vrc_renderer_last_kernel": (C.c_char_p, [_vp]),
     "vrc_ipc_export_image": (_int, [_vp, _vp]),
     "vrc_ipc_open_image": (_int, [_int, _vp, C.POINTER(_vp)]),
@@ -111,6 +113,7 @@ SYMBOLS = {
     "vrc_renderer_set_image_target": (_int, [_vp, _vp]),
     "vrc_ipc_flags_open": (_int, [C.c_char_p, _u32, _int, _int, C.POINTER(_vp)]),
     "vrc_ipc_flags_close": (_int, [_vp]),
+    "vrc_ipc_stream_wait": (_int, [_vp, _vp, _vp, _u32, _u32]),
     "vrc_stream_write_flag": (_int, [_vp, _u32, _u32, _vp]),
     "vrc_stream_wait_flag": (_int, [_vp, _u32, _u32, _vp]),
     "vrc_ipc_flag_value": (_u32, [_vp, _u32]),
@@ -133,10 +136,20 @@ def load():
         import torch  # noqa: F401
     except ImportError:
         pass
-    if not os.path.exists(LIB_PATH):
-        raise VrcError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+    path = LIB_PATH
+    variant = os.environ.get("VRC_LIB", "").strip()
+    if variant:
+        # an EXPERIMENT build of the same sources (tools/build_variant.py -> gpurun_variants/var_<name>.so) loaded in the
+        # product's place for an A/B -- never by overwriting the product library; said out loud, and bench.py records it
+        if not os.path.exists(variant):
+            raise VrcError(f"VRC_LIB={variant} does not exist")
+        import sys
+        print(f"cpuvoxelraycaster_amd: VRC_LIB set -- loading the experiment library {variant}, not the product {LIB_PATH}", file=sys.stderr)
+        path = variant
+    if not os.path.exists(path):
+        raise VrcError(f"{path} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(the HIP library is the product; there is no fallback)")
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(L, name)
         fn.restype = res

@@ -16,8 +16,12 @@
 #include <vector>
 #include "vrc_internal.h"
 
+#include <chrono>
+#include <thread>
+
 #include <errno.h>
 #include <fcntl.h>
+#include <signal.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -57,6 +61,7 @@ struct Tuning {
     uint32_t tail_units_per_wave = 4;   // automatic chunking: units of half the chunk for the last tiles (0 = off); tools/chunk_time.py
     bool reuse_invariant = false;       // pinhole camera: walk a unit's sample-invariant rays once (never a process default)
     bool walk_from_root = false;        // measurement switch: no ray starts below the root
+    uint32_t lane_samples = 0;          // lane <-> (pixel, sample) map of the stage-synchronous kernel: 0 = automatic, 1, 4
 };
 Tuning g_tuning;
 std::mutex g_tuning_mu;
@@ -200,6 +205,13 @@ extern "C" int vrc_renderer_set_walk_from_root(vrc_renderer* r, uint32_t on)
     if (!r) return fail(VRC_ERR_INVALID, "null renderer");
     if (on > 1) return fail(VRC_ERR_INVALID, "vrc_renderer_set_walk_from_root: on = %u (0 or 1)", on);
     r->tuning.walk_from_root = on != 0;
+    return VRC_OK;
+}
+extern "C" int vrc_renderer_set_lane_samples(vrc_renderer* r, uint32_t samples)
+{
+    if (!r) return fail(VRC_ERR_INVALID, "null renderer");
+    if (samples != 0 && samples != 1 && samples != 4) return fail(VRC_ERR_INVALID, "vrc_renderer_set_lane_samples: %u (0, 1 or 4)", samples);
+    r->tuning.lane_samples = samples;
     return VRC_OK;
 }
 extern "C" const char* vrc_renderer_last_kernel(const vrc_renderer* r) { return r ? r->last_kernel : ""; }
@@ -376,6 +388,19 @@ extern "C" int vrc_cast_rays(const vrc_scene* s, uint64_t n, const float* org_xy
                        });
 }
 
+extern "C" int vrc_cast_ray_chains(const vrc_scene* s, uint64_t n, const float* org_a_xyz, const float* dir_a_xyz, const float* org_b_xyz,
+                                   const float* dir_b_xyz, float coef_b, vrc_hit* out_a, vrc_hit* out_b, uint32_t* not_executed, void* stream)
+{
+    if (!s) return fail(VRC_ERR_INVALID, "vrc_cast_ray_chains: null scene");
+    if (n == 0) return VRC_OK;
+    if (!org_a_xyz || !dir_a_xyz || !org_b_xyz || !dir_b_xyz || !out_a || !out_b) return fail(VRC_ERR_INVALID, "vrc_cast_ray_chains: null buffer");
+    if (!(coef_b >= 0.0f && coef_b <= 0.5f)) return fail(VRC_ERR_INVALID, "vrc_cast_ray_chains: coef_b = %g outside [0, 0.5] (the start below the root is proven for those)", (double)coef_b);
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(vrc::launch_cast_ray_chains(s->d_nodes, (int)s->depth, n, org_a_xyz, dir_a_xyz, org_b_xyz, dir_b_xyz, coef_b, out_a, out_b,
+                                        not_executed, (hipStream_t)stream));
+    return VRC_OK;
+}
+
 // Camera::getClosestPoint (camera_controller.hpp:56-60, once per frame, main.cpp:115): the ray goes through the scene's
 // pinned slot -- the kernel reads it from host memory and writes the HitPoint back there; the call is a 32-byte store,
 // one launch on the scene's own stream, a wait for that stream and a 48-byte load.
@@ -475,7 +500,7 @@ extern "C" int vrc_renderer_create(const vrc_scene* s, uint32_t width, uint32_t 
     const uint64_t n = (uint64_t)width * height;
     hipError_t e = hipMalloc(&r->d_image, n * 4);
     if (e == hipSuccess) e = hipMalloc(&r->d_accum, n * 16);
-    const uint64_t n_tiles = (uint64_t)((width + 7u) / 8u) * ((height + 7u) / 8u);
+    const uint64_t n_tiles = (uint64_t)((width + 3u) / 4u) * ((height + 3u) / 4u);   // of the finest lane map (4 x 4 pixels)
     if (e == hipSuccess) e = hipMalloc(&r->d_stats, vrc::VRC_STATS_BYTES + 2 * vrc::VRC_QUEUE_BYTES);
     if (e == hipSuccess) e = hipMalloc((void**)&r->d_tile_done, n_tiles * 4);
     if (e == hipSuccess) e = hipMemset(r->d_accum, 0, n * 16);
@@ -583,8 +608,16 @@ int render_impl(vrc_renderer* r, const vrc_camera* cam, const vrc_frame_params* 
     }
     // checkerboard frames on the stage-synchronous kernel: 16 x 8 pixel tiles, 64 selected pixels each
     a.checker_wide = (tuning.kernel == VRC_KERNEL_SYNC && p->checker_parity >= 0) ? 1u : 0u;
-    const uint32_t tiles_per_row = a.checker_wide ? (r->width + 15u) / 16u : (r->width + 7u) / 8u;
-    const uint64_t items = (uint64_t)tiles_per_row * ((rows + 7u) / 8u) * 64ull;
+    // the lane <-> (pixel, sample) map (vrc_renderer_set_lane_samples): four samples abreast where the kernel has a build for it
+    // and the frame's samples divide by four -- the accumulators make the order of a pixel's samples immaterial, the 0.4 / 0.6
+    // blend of the non-sample mode (raycaster.hpp:79-85) does not
+    const bool can_s4 = tuning.kernel == VRC_KERNEL_SYNC && a.p.use_samples && a.p.spp % 4u == 0u && p->checker_parity < 0 &&
+                        a.p.gi_bounces <= 1u && !tuning.walk_from_root && !tuning.reuse_invariant &&
+                        (tuning.sample_chunk == 0u || tuning.sample_chunk % 4u == 0u);
+    a.lane_samples = (can_s4 && tuning.lane_samples != 1u) ? 4u : 1u;
+    const uint32_t tw = a.lane_samples == 4u ? 4u : 8u;
+    const uint32_t tiles_per_row = a.checker_wide ? (r->width + 15u) / 16u : (r->width + tw - 1u) / tw;
+    const uint64_t items = (uint64_t)tiles_per_row * ((rows + tw - 1u) / tw) * 64ull;
     if (items > 0xfffffff0ull) return fail(VRC_ERR_INVALID, "vrc_render_frame: frame too large");
     a.n_items = (uint32_t)items;
     a.chunk = tuning.chunk;
@@ -630,6 +663,7 @@ int render_impl(vrc_renderer* r, const vrc_camera* cam, const vrc_frame_params* 
         const bool whole_spp = a.p.use_samples && a.p.spp > 1 && tuning.sample_chunk >= a.p.spp;
         uint32_t waves = vrc::sync_waves_for(vrc::camera_is_pinhole(a.cam), a.p.gi_bounces <= 1, a.p.use_gi != 0, whole_spp,
                                              (uint64_t)a.n_items * a.p.spp, tuning.blocks_per_cu_set ? tuning.blocks_per_cu : 0u);
+        if (a.lane_samples == 4u) waves = vrc::sync_s4_waves(vrc::camera_is_pinhole(a.cam));
         if (waves > fit) waves = vrc::sync_max_blocks_per_cu();          // deep trees: the stacks of 8 workgroups do not fit a CU's LDS
         a.waves = waves;
         bpc = waves;
@@ -646,14 +680,18 @@ int render_impl(vrc_renderer* r, const vrc_camera* cam, const vrc_frame_params* 
         // (tools/chunk_time.py).
         const uint64_t tiles = a.n_items / 64, waves = cap * (VRC_RENDER_BLOCK / 64);
         uint32_t c = tuning.sample_chunk ? tuning.sample_chunk : a.p.spp;
-        if (!tuning.sample_chunk) {
+        if (c > a.p.spp) c = a.p.spp;
+        if (!tuning.sample_chunk && a.lane_samples == 4u) {
+            // four samples abreast: a unit's samples come in fours (a tile has 16 pixels, so there are four times the units)
+            while (c % 8u == 0u && tiles * (a.p.spp / c) < 48 * waves) c /= 2;
+        } else if (!tuning.sample_chunk) {
             while (c > 2 && tiles * ((a.p.spp + c - 1) / c) < 48 * waves) c = (c + 1) / 2;
             if (c == 2 && tiles * ((a.p.spp + 1) / 2) < 8 * waves) c = 1;
         }
         a.sample_chunk = c < a.p.spp ? c : 0;
         // shorter units for the tiles handed out last (about four per wave): halves the spread of the waves' end times
         uint64_t units = tiles * ((a.p.spp + c - 1) / c);
-        if (!tuning.sample_chunk && c >= 2 && tuning.tail_units_per_wave) {
+        if (!tuning.sample_chunk && c >= 2 && tuning.tail_units_per_wave && (a.lane_samples == 1u || c % 8u == 0u)) {
             const uint32_t ct = c / 2, cpt_tail = (a.p.spp + ct - 1) / ct;
             uint64_t tt = (uint64_t)tuning.tail_units_per_wave * waves / cpt_tail;
             if (tt > tiles) tt = tiles;
@@ -757,6 +795,25 @@ struct vrc_ipc_flags {
     bool owner = false;
     char name[96] = {0};
 };
+// the segment: `count` flags, then four words of header {magic, owner's pid, count, given up}
+constexpr uint32_t VRC_FLAGS_MAGIC = 0x56524346u;   // "VRCF"
+enum { FLAGS_HDR_MAGIC = 0, FLAGS_HDR_OWNER = 1, FLAGS_HDR_COUNT = 2, FLAGS_HDR_GIVEN_UP = 3, FLAGS_HDR_WORDS = 4 };
+
+static bool process_gone(int32_t pid)
+{
+    if (pid <= 0) return false;
+    if (kill((pid_t)pid, 0) != 0 && errno == ESRCH) return true;
+    // a child that exited but has not been reaped still has a pid: its state in /proc/<pid>/stat is Z
+    char path[64], buf[512];
+    snprintf(path, sizeof(path), "/proc/%d/stat", (int)pid);
+    FILE* fp = fopen(path, "r");
+    if (!fp) return false;
+    const size_t n = fread(buf, 1, sizeof(buf) - 1, fp);
+    fclose(fp);
+    buf[n] = 0;
+    const char* rp = strrchr(buf, ')');                        // "pid (comm) S ..."
+    return rp && rp[1] == ' ' && (rp[2] == 'Z' || rp[2] == 'X');
+}
 
 extern "C" int vrc_ipc_flags_open(const char* name, uint32_t count, int device, int create, vrc_ipc_flags** out)
 {
@@ -764,9 +821,30 @@ extern "C" int vrc_ipc_flags_open(const char* name, uint32_t count, int device, 
     if (name[0] != '/' || strlen(name) >= sizeof(vrc_ipc_flags::name)) return fail(VRC_ERR_INVALID, "vrc_ipc_flags_open: name must be \"/something\" (shm_open)");
     int rc = vrc::require_device(device, nullptr);
     if (rc) return rc;
-    const size_t page = 4096, bytes = (((size_t)count * 4u) + page - 1) / page * page;
+    const size_t page = 4096, bytes = (((size_t)(count + FLAGS_HDR_WORDS) * 4u) + page - 1) / page * page;
     int fd = create ? shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600) : shm_open(name, O_RDWR, 0600);
-    if (fd < 0 && create && errno == EEXIST) {                  // a segment of that name left by a run that died: the creator owns the name
+    if (fd < 0 && create && errno == EEXIST) {
+        // a segment of that name exists: replace it only when the process that made it is gone (a run that died) -- unlinking
+        // one that is in use would leave its processes waiting on memory nobody else maps
+        int32_t owner_pid = 0;
+        const int old = shm_open(name, O_RDONLY, 0600);
+        if (old >= 0) {
+            struct stat sb;
+            if (fstat(old, &sb) == 0 && sb.st_size >= (off_t)(FLAGS_HDR_WORDS * 4)) {
+                // the header sits behind the flags; its count word says where
+                void* m0 = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_SHARED, old, 0);
+                if (m0 != MAP_FAILED) {
+                    const uint32_t* w = (const uint32_t*)m0;
+                    const size_t words = (size_t)sb.st_size / 4u;
+                    for (size_t c = 0; c + FLAGS_HDR_WORDS <= words; ++c)        // find {magic, pid, count == c}
+                        if (w[c + FLAGS_HDR_MAGIC] == VRC_FLAGS_MAGIC && w[c + FLAGS_HDR_COUNT] == (uint32_t)c) { owner_pid = (int32_t)w[c + FLAGS_HDR_OWNER]; break; }
+                    munmap(m0, (size_t)sb.st_size);
+                }
+            }
+            close(old);
+        }
+        if (owner_pid > 0 && owner_pid != (int32_t)getpid() && !process_gone(owner_pid))
+            return fail(VRC_ERR_INVALID, "vrc_ipc_flags_open: %s is in use by process %d (give concurrent runs different names)", name, (int)owner_pid);
         shm_unlink(name);
         fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
     }
@@ -774,6 +852,14 @@ extern "C" int vrc_ipc_flags_open(const char* name, uint32_t count, int device, 
     if (create && ftruncate(fd, (off_t)bytes) != 0) {           // a new segment reads as zeros
         const int e = errno; close(fd); shm_unlink(name);
         return fail(VRC_ERR_INVALID, "vrc_ipc_flags_open: ftruncate: %s", strerror(e));
+    }
+    if (!create) {                                               // never map past what is there: that is a SIGBUS on first touch
+        struct stat sb;
+        if (fstat(fd, &sb) != 0 || sb.st_size < (off_t)bytes) {
+            close(fd);
+            return fail(VRC_ERR_INVALID, "vrc_ipc_flags_open: %s holds %lld bytes, %u flags need %zu (not created yet, or made for another count)",
+                        name, (long long)sb.st_size, count, bytes);
+        }
     }
     void* m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
     const int em = errno;
@@ -787,11 +873,52 @@ extern "C" int vrc_ipc_flags_open(const char* name, uint32_t count, int device, 
         if (create) shm_unlink(name);
         return fail(VRC_ERR_HIP, "vrc_ipc_flags_open: registering the segment: %s", hipGetErrorString(e));
     }
+    uint32_t* hdr = (uint32_t*)m + count;
+    if (create) {
+        hdr[FLAGS_HDR_OWNER] = (uint32_t)getpid(); hdr[FLAGS_HDR_COUNT] = count; hdr[FLAGS_HDR_GIVEN_UP] = 0u;
+        __atomic_store_n(hdr + FLAGS_HDR_MAGIC, VRC_FLAGS_MAGIC, __ATOMIC_RELEASE);
+    } else if (__atomic_load_n(hdr + FLAGS_HDR_MAGIC, __ATOMIC_ACQUIRE) != VRC_FLAGS_MAGIC || hdr[FLAGS_HDR_COUNT] != count) {
+        (void)hipHostUnregister(m);
+        munmap(m, bytes);
+        return fail(VRC_ERR_INVALID, "vrc_ipc_flags_open: %s was not made for %u flags", name, count);
+    }
     vrc_ipc_flags* f = new vrc_ipc_flags;
     f->device = device; f->count = count; f->bytes = bytes; f->host = (uint32_t*)m; f->dev = (uint32_t*)d; f->owner = create != 0;
     snprintf(f->name, sizeof(f->name), "%s", name);
     *out = f;
     return VRC_OK;
+}
+
+static bool flags_given_up(const vrc_ipc_flags* f) { return __atomic_load_n(f->host + f->count + FLAGS_HDR_GIVEN_UP, __ATOMIC_ACQUIRE) != 0u; }
+
+// the watchdog of a stream that waits for flags (include/vrc.h)
+extern "C" int vrc_ipc_stream_wait(vrc_ipc_flags* f, void* stream, const int32_t* pids, uint32_t n_pids, uint32_t timeout_ms)
+{
+    if (!f || (n_pids && !pids)) return fail(VRC_ERR_INVALID, "vrc_ipc_stream_wait: bad argument");
+    HIP_TRY(hipSetDevice(f->device));
+    const auto t0 = std::chrono::steady_clock::now();
+    const char* why = nullptr;
+    int32_t who = 0;
+    uint32_t spins = 0;
+    for (;;) {
+        const hipError_t q = hipStreamQuery((hipStream_t)stream);
+        if (q == hipSuccess) return flags_given_up(f) ? fail(VRC_ERR_PEER, "vrc_ipc_stream_wait: the exchange was given up (a peer died or timed out)") : VRC_OK;
+        if (q != hipErrorNotReady) return fail(VRC_ERR_HIP, "vrc_ipc_stream_wait: hipStreamQuery: %s", hipGetErrorString(q));
+        if (flags_given_up(f)) { why = "another process gave the exchange up"; break; }
+        if ((++spins & 63u) == 0u) {                               // the peers, every few milliseconds
+            for (uint32_t k = 0; k < n_pids && !why; ++k)
+                if (process_gone(pids[k])) { why = "a peer process is gone"; who = pids[k]; }
+            if (why) break;
+            const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+            if (timeout_ms && ms >= (long long)timeout_ms) { why = "timed out"; break; }
+        }
+        std::this_thread::sleep_for(std::chrono::microseconds(spins < 2000u ? 50 : 500));
+    }
+    // give up for everyone: mark the segment, then release every wait on its flags (>= comparisons: the largest value passes all)
+    __atomic_store_n(f->host + f->count + FLAGS_HDR_GIVEN_UP, 1u, __ATOMIC_RELEASE);
+    for (uint32_t i = 0; i < f->count; ++i) __atomic_store_n(f->host + i, 0xffffffffu, __ATOMIC_RELEASE);
+    (void)hipStreamSynchronize((hipStream_t)stream);              // drains now: nothing waits any more
+    return fail(VRC_ERR_PEER, "vrc_ipc_stream_wait: %s (pid %d); every wait on %s was released, frames after this are not valid", why, (int)who, f->name);
 }
 
 extern "C" int vrc_ipc_flags_close(vrc_ipc_flags* f)
@@ -808,6 +935,7 @@ extern "C" int vrc_ipc_flags_close(vrc_ipc_flags* f)
 extern "C" int vrc_stream_write_flag(vrc_ipc_flags* f, uint32_t index, uint32_t value, void* stream)
 {
     if (!f || index >= f->count) return fail(VRC_ERR_INVALID, "vrc_stream_write_flag: bad argument");
+    if (flags_given_up(f)) return fail(VRC_ERR_PEER, "vrc_stream_write_flag: the exchange on %s was given up", f->name);
     HIP_TRY(hipSetDevice(f->device));
     HIP_TRY(hipStreamWriteValue32((hipStream_t)stream, f->dev + index, value, 0));
     return VRC_OK;
@@ -816,6 +944,7 @@ extern "C" int vrc_stream_write_flag(vrc_ipc_flags* f, uint32_t index, uint32_t 
 extern "C" int vrc_stream_wait_flag(vrc_ipc_flags* f, uint32_t index, uint32_t value, void* stream)
 {
     if (!f || index >= f->count) return fail(VRC_ERR_INVALID, "vrc_stream_wait_flag: bad argument");
+    if (flags_given_up(f)) return fail(VRC_ERR_PEER, "vrc_stream_wait_flag: the exchange on %s was given up", f->name);
     HIP_TRY(hipSetDevice(f->device));
     HIP_TRY(hipStreamWaitValue32((hipStream_t)stream, f->dev + index, value, hipStreamWaitValueGte, 0xffffffffu));
     return VRC_OK;

@@ -73,6 +73,9 @@ struct FrameArgs {
     uint32_t walk_from_root;
     // host only: which build of the stage-synchronous kernel to launch, by waves per SIMD (6, 7 or 8; see sync_waves_for)
     uint32_t waves;
+    // which lane <-> (pixel, sample) map of the stage-synchronous kernel: 1 = 8 x 8 pixels, 4 = 4 x 4 pixels x 4 samples abreast
+    // (render_sync_body's NS); n_items then counts 64 lanes per 4 x 4 tile
+    uint32_t lane_samples;
     uint32_t* tile_done;
     uint32_t* resolve_dst;
     vrc_camera cam;
@@ -81,11 +84,14 @@ struct FrameArgs {
 
 hipError_t launch_cast_rays(const void* nodes, int depth, uint64_t n, const float* org, const float* dir,
                             const float* coef, const float* bias, vrc_hit* out, hipStream_t st);
+hipError_t launch_cast_ray_chains(const void* nodes, int depth, uint64_t n, const float* org_a, const float* dir_a, const float* org_b,
+                                  const float* dir_b, float coef_b, vrc_hit* out_a, vrc_hit* out_b, uint32_t* not_executed, hipStream_t st);
 hipError_t launch_grid_cast(const uint8_t* cells, int X, int Y, int Z, uint64_t n, const float* org, const float* dir,
                             vrc_hit* out, hipStream_t st);
 uint32_t tile_wave_lds_bytes();       // LDS job pool per wave of k_render_tile
 uint32_t tile_max_blocks_per_cu();    // register-limited workgroups per CU of k_render_tile
 uint32_t sync_max_blocks_per_cu();    // ... of k_render_sync
+uint32_t sync_s4_waves(bool pinhole); // waves per SIMD the samples-abreast builds were compiled for
 // The stage-synchronous kernels are built for 6 waves per SIMD (80 VGPRs), the lens one-bounce kernel also for 7 (72).
 // Rounds 2 and 3 shipped 7- and 8-wave builds of the pinhole kernels too, picked by a table (profiles/r03/sweep_waves.txt:
 // the 8-wave build won C3 with frames in flight by 2 %).  With walks that start below the root -- fewer iterations, two

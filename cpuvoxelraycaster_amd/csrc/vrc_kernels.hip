@@ -72,6 +72,67 @@ k_cast_rays_nolod(const uint2* __restrict__ nodes, int depth, uint64_t n, const 
     cast_rays_body<false>(nodes, depth, n, org, dir, nullptr, nullptr, out);
 }
 
+// Chains of two casts (vrc_cast_ray_chains): ray A from the root; ray B next to A's hit, started below the root on the path A's
+// walk left in the lane's stack column -- ray_setup / start_scale_next_to[_lod] / ray_start_below / ray_walk<.., BELOW> exactly as
+// the frame kernels use them for their shadow, GI and GI-shadow rays, here with the caller's origins and directions
+// (tests/test_gpu_start_below.py puts them k ulps either side of the planes of every scale).
+template <bool LOD>
+__device__ __forceinline__ void cast_ray_chains_body(const uint2* __restrict__ nodes, int depth, uint64_t n, const float* __restrict__ org_a,
+                                                     const float* __restrict__ dir_a, const float* __restrict__ org_b,
+                                                     const float* __restrict__ dir_b, float coef_b, vrc_hit* __restrict__ out_a,
+                                                     vrc_hit* __restrict__ out_b, uint32_t* __restrict__ not_executed)
+{
+    extern __shared__ stack_t lds_stack[];  // [depth][blockDim.x]
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    stack_t* stk = lds_stack + threadIdx.x;
+    const uint2 root = nodes[0];
+    float ox = org_a[3 * i + 0], oy = org_a[3 * i + 1], oz = org_a[3 * i + 2];
+    float dx = dir_a[3 * i + 0], dy = dir_a[3 * i + 1], dz = dir_a[3 * i + 2];
+    Ray r;
+    bool active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
+    ray_run<256, 0>(r, active, nodes, stk, depth, 0.0f, 0.0f);
+    Hit h;
+    ray_finish(r, depth, ox, oy, oz, dx, dy, dz, h);
+    uint4* o = reinterpret_cast<uint4*>(out_a + i);
+    o[0] = make_uint4(f2u(h.px), f2u(h.py), f2u(h.pz), f2u(h.nx));
+    o[1] = make_uint4(f2u(h.ny), f2u(h.nz), f2u(h.u), f2u(h.v));
+    o[2] = make_uint4(h.hit, h.node, f2u(h.distance), h.complexity);
+    ox = org_b[3 * i + 0]; oy = org_b[3 * i + 1]; oz = org_b[3 * i + 2];
+    dx = dir_b[3 * i + 0]; dy = dir_b[3 * i + 1]; dz = dir_b[3 * i + 2];
+    active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
+    uint32_t s0 = 22u;
+    if (h.hit)
+        s0 = LOD ? start_scale_next_to_lod(ox, oy, oz, h.px, h.py, h.pz, (h.hit >> 16) & 0xffu, dx, dy, dz)
+                 : start_scale_next_to(ox, oy, oz, h.px, h.py, h.pz, (h.hit >> 16) & 0xffu);
+    ray_start_below(r, s0, ox, oy, oz);
+    const uint32_t skipped = active ? (uint32_t)(SVO_MAX - 1 - r.scale) : 0u;
+    ray_run<256, LOD ? 1 : 0, true>(r, active, nodes, stk, depth, coef_b, 0.0f);
+    Hit g;
+    ray_finish(r, depth, ox, oy, oz, dx, dy, dz, g);
+    o = reinterpret_cast<uint4*>(out_b + i);
+    o[0] = make_uint4(f2u(g.px), f2u(g.py), f2u(g.pz), f2u(g.nx));
+    o[1] = make_uint4(f2u(g.ny), f2u(g.nz), f2u(g.u), f2u(g.v));
+    o[2] = make_uint4(g.hit, g.node, f2u(g.distance), g.complexity);
+    if (not_executed) not_executed[i] = skipped;
+}
+
+extern "C" __global__ void __launch_bounds__(256)
+k_cast_ray_chains(const uint2* __restrict__ nodes, int depth, uint64_t n, const float* __restrict__ org_a, const float* __restrict__ dir_a,
+                  const float* __restrict__ org_b, const float* __restrict__ dir_b, float coef_b, vrc_hit* __restrict__ out_a,
+                  vrc_hit* __restrict__ out_b, uint32_t* __restrict__ not_executed)
+{
+    cast_ray_chains_body<true>(nodes, depth, n, org_a, dir_a, org_b, dir_b, coef_b, out_a, out_b, not_executed);
+}
+
+extern "C" __global__ void __launch_bounds__(256)
+k_cast_ray_chains_nolod(const uint2* __restrict__ nodes, int depth, uint64_t n, const float* __restrict__ org_a, const float* __restrict__ dir_a,
+                        const float* __restrict__ org_b, const float* __restrict__ dir_b, vrc_hit* __restrict__ out_a,
+                        vrc_hit* __restrict__ out_b, uint32_t* __restrict__ not_executed)
+{
+    cast_ray_chains_body<false>(nodes, depth, n, org_a, dir_a, org_b, dir_b, 0.0f, out_a, out_b, not_executed);
+}
+
 // ---------------------------------------------------------------------------
 // G1: dense grid DDA
 // ---------------------------------------------------------------------------
@@ -829,6 +890,12 @@ k_render_tile(const FrameArgs a)
 // entries from one row of a stack to the next: the sync kernels keep two stacks with interleaved rows (render_sync_body)
 #define VRC_SYNC_ROW (2 * VRC_RENDER_BLOCK)
 
+#ifndef VRC_SYNC_S4_WAVES
+#define VRC_SYNC_S4_WAVES 6          // waves per SIMD the samples-abreast kernels are built for (pinhole / lens)
+#endif
+#ifndef VRC_SYNC_S4_WAVES_LENS
+#define VRC_SYNC_S4_WAVES_LENS 6
+#endif
 #ifndef VRC_SYNC_MIN_WAVES
 #define VRC_SYNC_MIN_WAVES 6
 #endif
@@ -1036,7 +1103,15 @@ __device__ __forceinline__ uint32_t albedo_of(const uint8_t* tex, const Hit& h)
 // Then a pixel's camera ray is the same for every sample, and so are its primary hit, albedo and shadow ray(s): a work
 // unit sets them up ONCE and walks them once per sample of the unit (every ray the reference casts is still walked and
 // counted; only the identical arithmetic around the walks is not repeated).  The per-sample work is the GI pair.
-template <bool PINHOLE, bool ONE_BOUNCE, bool FUSED, bool FROM_ROOT = false>
+//
+// NS: the lane <-> (pixel, sample) map of a wave.  NS = 1: 8 x 8 pixels, the wave loops over the samples of its unit.  NS = 4
+// ("samples abreast"): 4 x 4 pixels x 4 samples -- lane = pixel + 16 * (sample % 4) -- for sample-mode frames whose spp is a
+// multiple of 4 (the host's choice, vrc_api.cpp).  The image cannot tell (counter_rand is keyed by the global pixel and the
+// sample, the sums are integers), the walks can: the four lanes of a pixel share the primary hit, so a stage's longest ray is
+// the longest of 16 neighbouring pixels' instead of 64 and a round issues fewer of the loop's blocks -- 6-11 % fewer VALU
+// instructions in the walks of the C3 frame, 4 % with a lens (tests/tools/tile_shape.py -> profiles/r04/tile_shape.json).
+// Every ray the reference casts is still walked and counted, each by its own lane.
+template <bool PINHOLE, bool ONE_BOUNCE, bool FUSED, bool FROM_ROOT = false, uint32_t NS = 1u>
 __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
 {
     // [depth][2][256] two stacks, their rows interleaved | 1536 B textures | 4 waves x 4 counters | camera paths (8 x 16 entries + 8) |
@@ -1087,7 +1162,10 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
     // Checkerboard frames (main.cpp:137,143: every other pixel of each swarm area) use tiles of 16 x 8 pixels, of
     // which a lane takes the selected pixel of its pair, so that all 64 lanes of a wave have work
     const bool checker = a.checker_wide != 0u;
-    const uint32_t tiles_per_row = checker ? (W + 15u) / 16u : (W + 7u) / 8u;
+    static_assert(NS == 1u || NS == 4u, "lane maps: 8 x 8 pixels, or 4 x 4 pixels x 4 samples");
+    constexpr uint32_t TW = NS == 4u ? 4u : 8u;                          // a wave's tile is TW x TW pixels
+    const uint32_t sub = NS == 1u ? 0u : lane >> 4;                      // which of the NS samples abreast this lane takes
+    const uint32_t tiles_per_row = checker ? (W + 15u) / 16u : (W + TW - 1u) / TW;
     const uint32_t n_tiles = a.n_items >> 6;
     const bool sharded = a.p.row_block && a.p.shard_count > 1u;
     constexpr bool pinhole = PINHOLE;     // see launch_render for the host's predicate
@@ -1164,8 +1242,8 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
         const uint32_t tile = (in_tail ? head_tiles : 0u) + u / chunks_per_tile;
         const uint32_t s_begin = (u % chunks_per_tile) * chunk, s_end = min(spp, s_begin + chunk);
         const uint32_t tx = tile % tiles_per_row, ty = tile / tiles_per_row;
-        uint32_t px_x = tx * 8u + (lane & 7u);
-        uint32_t px_y = ty * 8u + (lane >> 3);
+        uint32_t px_x = tx * TW + (lane & (TW - 1u));
+        uint32_t px_y = ty * TW + ((lane / TW) & (TW - 1u));
         if (sharded) px_y = ((px_y / a.p.row_block) * a.p.shard_count + a.p.shard_index) * a.p.row_block + (px_y % a.p.row_block);
         if (checker) {
             // the pixel of the pair (2c, 2c + 1) that pixel_selected accepts in this row: x = (y - y0 + parity) mod 2
@@ -1176,7 +1254,7 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
         const uint32_t pix = px_y * W + px_x;
         uint32_t acc_r = 0u, acc_g = 0u, acc_b = 0u;
 
-        if constexpr (PINHOLE) {
+        if constexpr (PINHOLE && NS == 1u) {
             // ---- the stages that do not depend on the sample: set up once, walked once per sample of the unit
             const uint32_t n_samples = s_end - s_begin;
             // the reference walks the identical primary and shadow ray again for every sample, and so does this kernel
@@ -1279,13 +1357,14 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
                 }
             }
         } else {
-            for (uint32_t sample = s_begin; sample < s_end; ++sample) {
+            for (uint32_t s0 = s_begin; s0 < s_end; s0 += NS) {
+                const uint32_t sample = s0 + sub;                                    // NS samples abreast: this lane's
                 const uint32_t fr = a.p.frame_index + sample;
                 uint32_t color = 0u;                                                 // ColorResult: Black
 #ifdef VRC_PROBE
                 uint32_t probe_c0 = 0u, probe_c1 = 0u, probe_c2 = 0u, probe_c3 = 0u;
 #endif
-                if (valid) {
+                if (valid && (NS == 1u || sample < s_end)) {
                     // R0: main.cpp:133,145-149; camera_controller.hpp:34-54
                     const float aspect_ratio = (float)W / (float)H;
                     const float lens_x = (float)px_x / (float)H - aspect_ratio * 0.5f;
@@ -1314,11 +1393,18 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
                     float oz = (a.cam.position[2] + wz) * inv_size + 1.0f;
                     Ray r;
                     bool active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
-                    // the lens point is next to the camera position: it starts where their paths from the root part
-                    copy_camera_path<VRC_SYNC_ROW>(stk, cam_path, depth, cam_scale);
-                    ray_start_below(r, start_scale_next_to(ox, oy, oz, (a.cam.position[0] + 0.0f) * inv_size + 1.0f,
-                                                           (a.cam.position[1] + 0.0f) * inv_size + 1.0f,
-                                                           (a.cam.position[2] + 0.0f) * inv_size + 1.0f, cam_scale), ox, oy, oz);
+                    if constexpr (PINHOLE) {
+                        // every camera ray starts at the camera, on the path of its direction signs
+                        const stack_t* const my_cam_path = cam_path + (r.mirror ^ 7u) * 16u;
+                        ray_start_at_camera(r, cam_scale < 22u ? my_cam_path[15] : 22u, ox, oy, oz);
+                        copy_camera_path<VRC_SYNC_ROW>(stk, my_cam_path, depth, cam_scale);
+                    } else {
+                        // the lens point is next to the camera position: it starts where their paths from the root part
+                        copy_camera_path<VRC_SYNC_ROW>(stk, cam_path, depth, cam_scale);
+                        ray_start_below(r, start_scale_next_to(ox, oy, oz, (a.cam.position[0] + 0.0f) * inv_size + 1.0f,
+                                                               (a.cam.position[1] + 0.0f) * inv_size + 1.0f,
+                                                               (a.cam.position[2] + 0.0f) * inv_size + 1.0f, cam_scale), ox, oy, oz);
+                    }
                     if (a.prim) {                                                   // the capture records the ray's own complexity
                         const uint32_t not_executed = book_not_executed(ctr, active, r);
                         ray_run<VRC_SYNC_ROW, 0, true>(r, active, nodes, stk, depth, 0.0f, 0.0f);
@@ -1376,8 +1462,14 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
 #endif
             }
         }
+        if constexpr (NS == 4u) {
+            // the four samples of a pixel sit 16 lanes apart: every lane of the pixel gets their sum, the first one books it
+            acc_r += __shfl_xor(acc_r, 16); acc_g += __shfl_xor(acc_g, 16); acc_b += __shfl_xor(acc_b, 16);
+            acc_r += __shfl_xor(acc_r, 32); acc_g += __shfl_xor(acc_g, 32); acc_b += __shfl_xor(acc_b, 32);
+        }
+        const bool writer = valid && sub == 0u;                                      // the lane that owns the pixel's sums
         if (a.p.use_samples && !FUSED) {                                             // raycaster.hpp:87-90
-            if (valid) {
+            if (writer) {
                 if (chunks_per_tile == 1u) {
                     uint4* ap = reinterpret_cast<uint4*>(a.accum) + pix;
                     uint4 v = *ap;
@@ -1395,12 +1487,12 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
             // Fused resolve: samples_to_image (raycaster.hpp:94-103: uint8(sum / count)), the shard pack and resetSamples
             // (:105-116) for this tile, done by whichever of the tile's work units finishes last.  The accumulators are
             // zero between frames in this mode, so a tile whose samples are all in one unit never touches them.
-            const uint32_t compact_row = ty * 8u + (lane >> 3);               // row inside this shard's packed buffer
+            const uint32_t compact_row = ty * TW + ((lane / TW) & (TW - 1u));   // row inside this shard's packed buffer
             bool resolve = true;
             uint32_t sum_r = acc_r, sum_g = acc_g, sum_b = acc_b, count = s_end - s_begin;
             if (chunks_per_tile != 1u) {
                 unsigned long long* ap = reinterpret_cast<unsigned long long*>(a.accum + 4ull * pix);
-                if (valid) {
+                if (writer) {
                     atomicAdd(ap + 0, (unsigned long long)acc_r | ((unsigned long long)acc_g << 32));
                     atomicAdd(ap + 1, (unsigned long long)acc_b | ((unsigned long long)(s_end - s_begin) << 32));
                 }
@@ -1416,7 +1508,7 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
                 arrived = __builtin_amdgcn_readfirstlane(arrived);
                 resolve = arrived == chunks_per_tile;
                 if (resolve) {
-                    if (valid) {
+                    if (writer) {
                         const unsigned long long rg = atomicExch(ap + 0, 0ull);
                         const unsigned long long bc = atomicExch(ap + 1, 0ull);
                         sum_r = (uint32_t)rg; sum_g = (uint32_t)(rg >> 32); sum_b = (uint32_t)bc; count = (uint32_t)(bc >> 32);
@@ -1424,7 +1516,7 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
                     if (lane == 0u) atomicExch(tile_done + tile, 0u);                             // ... and for the tile
                 }
             }
-            if (resolve && valid) {
+            if (resolve && writer) {
                 uint32_t c = 0xff000000u;
                 if (count) c |= (sum_r / count) | ((sum_g / count) << 8) | ((sum_b / count) << 16);
                 reinterpret_cast<uint32_t*>(a.image)[pix] = c;
@@ -1468,11 +1560,12 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
 // kernels: gi_chain is straight-line code there, which is worth a third of the register spills.  The ..._resolved
 // kernels are the same four with the fused resolve (vrc_render_frame_resolved) compiled in; the plain ones do not
 // carry its code or its arguments' registers.
-#define VRC_SYNC_KERNEL(name, PINHOLE, ONE_BOUNCE, FUSED, WAVES)                                   \
+#define VRC_SYNC_KERNEL_NS(name, PINHOLE, ONE_BOUNCE, FUSED, WAVES, NS)                            \
     extern "C" __global__ void __launch_bounds__(VRC_RENDER_BLOCK, WAVES) name(const FrameArgs a)  \
     {                                                                                              \
-        render_sync_body<PINHOLE, ONE_BOUNCE, FUSED>(a);                                           \
+        render_sync_body<PINHOLE, ONE_BOUNCE, FUSED, false, NS>(a);                                \
     }
+#define VRC_SYNC_KERNEL(name, PINHOLE, ONE_BOUNCE, FUSED, WAVES) VRC_SYNC_KERNEL_NS(name, PINHOLE, ONE_BOUNCE, FUSED, WAVES, 1u)
 VRC_SYNC_KERNEL(k_render_sync, false, true, false, VRC_SYNC_MIN_WAVES)
 VRC_SYNC_KERNEL(k_render_sync2, false, false, false, VRC_SYNC_MIN_WAVES)
 VRC_SYNC_KERNEL(k_render_sync_pinhole, true, true, false, VRC_SYNC_MIN_WAVES)
@@ -1486,7 +1579,13 @@ VRC_SYNC_KERNEL(k_render_sync_pinhole2_resolved, true, false, true, VRC_SYNC_MIN
 // 6-wave build ties or beats them on every configuration and pose (profiles/r03/sweep_waves_below.txt), without their spills.
 VRC_SYNC_KERNEL(k_render_sync_w7, false, true, false, 7)
 VRC_SYNC_KERNEL(k_render_sync_resolved_w7, false, true, true, 7)
+// four samples abreast (NS = 4, see render_sync_body): the one-bounce kernels, for sample-mode frames with spp % 4 == 0
+VRC_SYNC_KERNEL_NS(k_render_sync_s4, false, true, false, VRC_SYNC_S4_WAVES_LENS, 4u)
+VRC_SYNC_KERNEL_NS(k_render_sync_resolved_s4, false, true, true, VRC_SYNC_S4_WAVES_LENS, 4u)
+VRC_SYNC_KERNEL_NS(k_render_sync_pinhole_s4, true, true, false, VRC_SYNC_S4_WAVES, 4u)
+VRC_SYNC_KERNEL_NS(k_render_sync_pinhole_resolved_s4, true, true, true, VRC_SYNC_S4_WAVES, 4u)
 #undef VRC_SYNC_KERNEL
+#undef VRC_SYNC_KERNEL_NS
 // the pinhole one-bounce kernels with every ray started at the root, as lsvo.hpp:60-72 does (vrc_renderer_set_walk_from_root: a
 // measurement switch -- bench.py's extra.every_ray_from_the_root says what the start below the root is worth)
 extern "C" __global__ void __launch_bounds__(VRC_RENDER_BLOCK, VRC_SYNC_MIN_WAVES) k_render_sync_pinhole_from_root(const FrameArgs a)
@@ -1659,6 +1758,22 @@ hipError_t launch_cast_rays(const void* nodes, int depth, uint64_t n, const floa
     return hipGetLastError();
 }
 
+hipError_t launch_cast_ray_chains(const void* nodes, int depth, uint64_t n, const float* org_a, const float* dir_a, const float* org_b,
+                                  const float* dir_b, float coef_b, vrc_hit* out_a, vrc_hit* out_b, uint32_t* not_executed, hipStream_t st)
+{
+    if (n == 0) return hipSuccess;
+    const int block = 256;
+    const uint64_t grid = (n + block - 1) / block;
+    const size_t lds = (size_t)depth * block * sizeof(stack_t);
+    if (coef_b == 0.0f)
+        hipLaunchKernelGGL(k_cast_ray_chains_nolod, dim3((uint32_t)grid), dim3(block), lds, st, (const uint2*)nodes, depth, n, org_a, dir_a,
+                           org_b, dir_b, out_a, out_b, not_executed);
+    else
+        hipLaunchKernelGGL(k_cast_ray_chains, dim3((uint32_t)grid), dim3(block), lds, st, (const uint2*)nodes, depth, n, org_a, dir_a,
+                           org_b, dir_b, coef_b, out_a, out_b, not_executed);
+    return hipGetLastError();
+}
+
 hipError_t launch_grid_cast(const uint8_t* cells, int X, int Y, int Z, uint64_t n, const float* org, const float* dir,
                             vrc_hit* out, hipStream_t st)
 {
@@ -1672,6 +1787,7 @@ hipError_t launch_grid_cast(const uint8_t* cells, int X, int Y, int Z, uint64_t 
 uint32_t tile_wave_lds_bytes() { return TILE_WAVE_LDS; }
 uint32_t tile_max_blocks_per_cu() { return VRC_TILE_MIN_WAVES; }
 uint32_t sync_max_blocks_per_cu() { return VRC_SYNC_MIN_WAVES; }
+uint32_t sync_s4_waves(bool pinhole) { return pinhole ? VRC_SYNC_S4_WAVES : VRC_SYNC_S4_WAVES_LENS; }
 uint32_t sync_waves_for(bool pinhole, bool one_bounce, bool use_gi, bool whole_spp_units, uint64_t pixel_samples, uint32_t requested)
 {
     // the builds that exist: 6 for every kernel; the lens one-bounce kernel also 7
@@ -1715,7 +1831,10 @@ hipError_t launch_render(const FrameArgs& a, uint32_t grid_blocks, int kernel, h
         const uint32_t waves = a.waves;
         struct Build { void (*fn)(const FrameArgs); const char* name; };
 #define VRC_BUILD(k) Build{k, #k}
+        const bool s4 = a.lane_samples == 4u && one;
         const Build b =
+            s4 ? (pinhole ? (fused ? VRC_BUILD(k_render_sync_pinhole_resolved_s4) : VRC_BUILD(k_render_sync_pinhole_s4))
+                          : (fused ? VRC_BUILD(k_render_sync_resolved_s4) : VRC_BUILD(k_render_sync_s4))) :
             (waves == 7u && !pinhole && one) ? (fused ? VRC_BUILD(k_render_sync_resolved_w7) : VRC_BUILD(k_render_sync_w7)) :
             (a.walk_from_root && pinhole && one) ? (fused ? VRC_BUILD(k_render_sync_pinhole_resolved_from_root) : VRC_BUILD(k_render_sync_pinhole_from_root)) :
             pinhole ? (one ? (fused ? VRC_BUILD(k_render_sync_pinhole_resolved) : VRC_BUILD(k_render_sync_pinhole))

@@ -87,10 +87,16 @@ class PeerFrames:
     stream order: written[slot][k] = 1 + the last frame whose rows rank k has put into framebuffer `slot` (rank 0's stream
     waits for it before the frame is read), consumed[slot] = 1 + the last frame of that framebuffer rank 0 has consumed (the
     writers' streams wait for it before the next frame goes in).  A wait names a value, so the hosts exchange nothing per
-    frame; the image handles travel once, at set-up, through all_gather_object on `group` (any backend)."""
+    frame; the image handles travel once, at set-up, through all_gather_object on `group` (any backend).
+
+    A stream-ordered wait has no timeout: a stream that waits for a rank that died waits for ever, and so does every
+    synchronize on it.  So the hosts never synchronise these streams blindly: `wait(streams)` is the watchdog
+    (include/vrc.h: vrc_ipc_stream_wait) -- it polls the streams, the peers' process ids and a deadline, and when a peer is gone
+    it releases every wait on the flags in every process, lets the streams drain and raises."""
 
     def __init__(self, renderers, device, rank, world, group, name):
         import ctypes as C
+        import os
         import torch.distributed as dist
         from . import capi
         L = capi.load()
@@ -99,10 +105,15 @@ class PeerFrames:
         F = self.F = len(renderers)
         self._flags = C.c_void_p()
         n = F * world + F                                      # written[slot][rank] then consumed[slot]
+        # the name carries the creator's pid: two runs on one node never share a segment (the creator tells the others)
+        name = "%s_%d" % (name, os.getpid()) if rank == 0 else None
         if rank == 0:
             capi.check(L.vrc_ipc_flags_open(name.encode(), n, device, 1, C.byref(self._flags)))
         everyone = [None] * world
-        dist.all_gather_object(everyone, [r.exportImage() for r in renderers] if rank == 0 else None, group=group)
+        dist.all_gather_object(everyone, ([r.exportImage() for r in renderers], name, os.getpid()) if rank == 0 else (None, None, os.getpid()), group=group)
+        name = everyone[0][1]
+        self.pids = [e[2] for k, e in enumerate(everyone) if k != rank]      # the peers this rank's streams may wait for
+        everyone = [e[0] for e in everyone]
         self.targets = []
         if rank != 0:
             capi.check(L.vrc_ipc_flags_open(name.encode(), n, device, 0, C.byref(self._flags)))
@@ -140,6 +151,16 @@ class PeerFrames:
         from . import capi
         if self.rank == 0:
             capi.check(capi.load().vrc_stream_write_flag(self._flags, self._consumed(frame % self.F), frame + 1, capi.ptr(stream)))
+
+    def wait(self, streams, timeout_s=120.0):
+        """Instead of synchronising `streams` (raw stream pointers): returns when everything enqueued on them has completed;
+        raises VrcError (VRC_ERR_PEER) when a peer process is gone or nothing completes for timeout_s -- every wait on the flags
+        is then released in every process, so nobody hangs; the frames in flight are lost."""
+        import ctypes as C
+        from . import capi
+        pids = (C.c_int32 * len(self.pids))(*self.pids)
+        for s in streams:
+            capi.check(capi.load().vrc_ipc_stream_wait(self._flags, capi.ptr(s), pids, len(self.pids), int(timeout_s * 1000)))
 
     def close(self):
         """after every rank has synchronised its streams (the caller's barrier)"""

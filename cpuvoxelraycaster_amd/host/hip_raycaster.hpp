@@ -234,6 +234,7 @@ public:
     void setSampleChunk(uint32_t samples_per_unit) { check(vrc_renderer_set_sample_chunk(r_, samples_per_unit), "vrc_renderer_set_sample_chunk"); }
     // ... and, beyond the reference, the sample-invariant primary / shadow walks of a pinhole camera done once per unit
     void setInvariantRayReuse(bool on) { check(vrc_renderer_set_invariant_ray_reuse(r_, on ? 1u : 0u), "vrc_renderer_set_invariant_ray_reuse"); }
+    void setLaneSamples(uint32_t samples) { check(vrc_renderer_set_lane_samples(r_, samples), "vrc_renderer_set_lane_samples"); }
     void setWalkFromRoot(bool on) { check(vrc_renderer_set_walk_from_root(r_, on ? 1u : 0u), "vrc_renderer_set_walk_from_root"); }
 
     void samples_to_image(void* stream = nullptr) { check(vrc_samples_to_image(r_, stream), "vrc_samples_to_image"); }   // raycaster.hpp:94
@@ -344,6 +345,14 @@ public:
     uint32_t nextSlot() const { return (uint32_t)(n_ % slots_.size()); }     // the slot (and stream) the next submit() uses
     void wait(uint32_t slot) { check(vrc_stream_synchronize(device_, streams_[slot]), "vrc_stream_synchronize"); }
     void waitAll() { for (uint32_t i = 0; i < slots_.size(); ++i) wait(i); }
+    // waitAll() for streams that wait for peers' frame flags (direct peer writes): never a blind synchronize -- a stream-ordered
+    // wait has no timeout.  Polls the streams, the peers' process ids and a deadline (vrc_ipc_stream_wait); when a peer is gone
+    // every wait on the flags is released in every process and this throws (VRC_ERR_PEER).
+    void waitAllWatched(vrc_ipc_flags* flags, const std::vector<int32_t>& peer_pids, uint32_t timeout_ms = 120000)
+    {
+        for (void* st : streams_)
+            check(vrc_ipc_stream_wait(flags, st, peer_pids.data(), (uint32_t)peer_pids.size(), timeout_ms), "vrc_ipc_stream_wait");
+    }
     std::vector<uint8_t> image(uint32_t slot) { return slots_[slot]->render_image(streams_[slot]); }   // waits for that slot
     void* image_device_ptr(uint32_t slot) const { return vrc_image_device_ptr(slots_[slot]->handle()); }
     void* stream(uint32_t slot) const { return streams_[slot]; }

@@ -115,6 +115,11 @@ class LSVO:
         check(capi.load().vrc_cast_rays(self._h, n, ptr(org_ptr), ptr(dir_ptr), ptr(coef_ptr), ptr(bias_ptr),
                                         ptr(out_ptr), capi.VRC_MEM_DEVICE, ptr(stream)))
 
+    def castRayChainsDevice(self, n, org_a_ptr, dir_a_ptr, org_b_ptr, dir_b_ptr, coef_b, out_a_ptr, out_b_ptr, not_executed_ptr=None, stream=None):
+        """ray A from the root, then ray B started below the root next to A's hit (include/vrc.h: vrc_cast_ray_chains)"""
+        check(capi.load().vrc_cast_ray_chains(self._h, n, ptr(org_a_ptr), ptr(dir_a_ptr), ptr(org_b_ptr), ptr(dir_b_ptr), float(coef_b),
+                                              ptr(out_a_ptr), ptr(out_b_ptr), ptr(not_executed_ptr), ptr(stream)))
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
             capi.load().vrc_scene_destroy(self._h)
@@ -215,6 +220,11 @@ class RayCaster:
     def setWalkFromRoot(self, on=True):
         """Measurement switch: every ray from the root (none starts below it).  include/vrc.h: vrc_renderer_set_walk_from_root."""
         check(capi.load().vrc_renderer_set_walk_from_root(self._h, 1 if on else 0))
+
+    def setLaneSamples(self, samples=0):
+        """lane <-> (pixel, sample) map of the frame kernel: 1 = 8 x 8 pixels per wave, 4 = 4 x 4 pixels x 4 samples abreast,
+        0 = the library's choice.  Same results either way.  include/vrc.h: vrc_renderer_set_lane_samples."""
+        check(capi.load().vrc_renderer_set_lane_samples(self._h, samples))
 
     def setInvariantRayReuse(self, on=True):
         """beyond the reference: pinhole camera, walk a work unit's primary and shadow ray once instead of once per sample

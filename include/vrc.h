@@ -33,6 +33,7 @@ extern "C" {
 #define VRC_ERR_NO_DEVICE    -2   /* no HIP device / HIP runtime error at init */
 #define VRC_ERR_HIP          -3   /* HIP runtime call failed (see vrc_last_error) */
 #define VRC_ERR_OOM          -4
+#define VRC_ERR_PEER         -5   /* a peer process of a direct-peer-write exchange died or timed out (vrc_ipc_stream_wait) */
 
 #define VRC_MEM_HOST   0
 #define VRC_MEM_DEVICE 1
@@ -134,6 +135,19 @@ int vrc_cast_rays(const vrc_scene *s, uint64_t n,
                   const float *org_xyz, const float *dir_xyz,
                   const float *coef, const float *bias,
                   vrc_hit *out, int mem, void *stream);
+
+/* Chains of two casts, the way RayCaster::castRay chains them (raycaster.hpp:131 -> :153; :194 ->
+ * :198): ray A as vrc_cast_rays casts it (coefficient and bias 0), then ray B -- origin next to A's
+ * hit -- cast with ray_size_coef = coef_b (0 <= coef_b <= 0.5; bias 0) and STARTED BELOW THE ROOT on
+ * the path A's walk left, exactly as the frame kernels start their shadow / GI / GI-shadow rays
+ * (csrc/vrc_device.h: start_scale_next_to[_lod]); where A missed, B starts at the root.  out_b[i]
+ * equals vrc_cast_rays of ray B alone bit for bit (complexity included: the iterations a start below
+ * the root leaves out are counted, lsvo.hpp:73); not_executed[i] (may be NULL) = how many those were.
+ * Device buffers only (as VRC_MEM_DEVICE above); asynchronous on `stream`. */
+int vrc_cast_ray_chains(const vrc_scene *s, uint64_t n,
+                        const float *org_a_xyz, const float *dir_a_xyz,
+                        const float *org_b_xyz, const float *dir_b_xyz, float coef_b,
+                        vrc_hit *out_a, vrc_hit *out_b, uint32_t *not_executed, void *stream);
 
 /* Single-ray form for Camera::getClosestPoint (camera_controller.hpp:56-60). Synchronous; thread-safe
  * (calls on one scene are serialised).  Uses a pinned slot and a stream owned by the scene: no
@@ -252,7 +266,20 @@ int vrc_ipc_open_image(int device, const vrc_ipc_handle *handle, void **image_de
 int vrc_ipc_close_image(int device, void *image_dev);
 /* image_dev: RGBA8 width x height of this renderer's size on any device this one can reach; NULL = the renderer's own image. */
 int vrc_renderer_set_image_target(vrc_renderer *r, void *image_dev);
-int vrc_ipc_flags_open(const char *name, uint32_t count, int device, int create, vrc_ipc_flags **out);   /* zeros when created */
+/* create = 1: makes the segment (zeros) and records this process as its owner; a segment of that name that already
+ * exists is replaced only when its owner is gone (a run that died) -- one that is still in use is VRC_ERR_INVALID, so give
+ * concurrent runs different names (a pid or a token in it).  create = 0: opens it; a segment that is smaller than `count`
+ * asks for or was made for another count is VRC_ERR_INVALID, never a fault on first touch. */
+int vrc_ipc_flags_open(const char *name, uint32_t count, int device, int create, vrc_ipc_flags **out);
+/* A stream-ordered wait (vrc_stream_wait_flag) HAS NO TIMEOUT: if the process that should write the flag died, the stream --
+ * and every hipStreamSynchronize on it -- waits for ever.  So a host never synchronises such a stream blindly; it calls
+ * vrc_ipc_stream_wait: polls `stream` until everything enqueued on it has completed (VRC_OK), or until one of the peers
+ * `pids` (process ids on this node, n_pids of them; may be NULL) no longer exists, or `timeout_ms` have passed, or another
+ * process has already given up on this segment.  On those three it gives up for everyone: marks the segment and writes
+ * 0xffffffff into every flag from the host, which releases every wait on them in every process, lets the stream drain and
+ * returns VRC_ERR_PEER (frames completed after that are not valid; vrc_stream_wait_flag / _write_flag on a marked segment
+ * fail with VRC_ERR_PEER as well).  Start a fresh process to try again. */
+int vrc_ipc_stream_wait(vrc_ipc_flags *f, void *stream, const int32_t *pids, uint32_t n_pids, uint32_t timeout_ms);
 int vrc_ipc_flags_close(vrc_ipc_flags *f);                     /* the creator also removes the segment */
 int vrc_stream_write_flag(vrc_ipc_flags *f, uint32_t index, uint32_t value, void *stream);
 int vrc_stream_wait_flag(vrc_ipc_flags *f, uint32_t index, uint32_t value, void *stream);      /* until flag >= value */
@@ -362,6 +389,15 @@ int vrc_renderer_set_invariant_ray_reuse(vrc_renderer *r, uint32_t on);
  * vrc_frame_stats.rays / sum_complexity either way; iterations_not_executed is 0 with it.  (bench.py
  * reports the frame time with it as extra.every_ray_from_the_root.) */
 int vrc_renderer_set_walk_from_root(vrc_renderer *r, uint32_t on);
+/* The lane <-> (pixel, sample) map of the stage-synchronous kernel.  The reference's own map of
+ * pixels to workers is the static 4 x 4 area grid of main.cpp:140-143; results do not depend on
+ * it there or here.  samples = 1: a wave takes 8 x 8 pixels and loops over the samples of its work
+ * unit.  samples = 4: a wave takes 4 x 4 pixels with four samples of each side by side (the four
+ * lanes of a pixel share its primary hit: a stage's longest ray is the longest of 16 neighbouring
+ * pixels', not of 64) -- for sample-mode frames (use_samples) with spp a multiple of 4, one GI
+ * bounce and no checkerboard; other frames use map 1 whatever is set.  samples = 0 (default): the
+ * library's choice.  Image, accumulators, captures and vrc_frame_stats are the same either way. */
+int vrc_renderer_set_lane_samples(vrc_renderer *r, uint32_t samples);
 
 #ifdef __cplusplus
 }

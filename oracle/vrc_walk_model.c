@@ -42,6 +42,9 @@
 #endif
 
 int orc_model_descend_by_position = 0;     /* study switch: see model_cast */
+/* The margin as a run-time switch (tests/test_walk_model.py::test_constructed_margin_adversaries runs the model at 0..8 ulps to
+ * record where it first holds against the oracle); the kernel's is the constant 8 of vrc_device.h: start_scale_next_to. */
+uint32_t orc_model_margin = ORC_MARGIN;
 
 typedef struct orc_walk_state {
     uint32_t rows[24];      /* parent index by scale (the LDS stack column of a lane) */
@@ -80,7 +83,7 @@ void orc_model_camera_paths(const orc_lnode *raw, uint32_t depth, const float ca
     uint32_t mb = 0u;
     int inside = 1;
     for (int i = 0; i < 3; i++) {
-        if (!((out->onplane >> i) & 1u)) mb |= (a[i] - ORC_MARGIN) ^ (a[i] + ORC_MARGIN);
+        if (!((out->onplane >> i) & 1u)) mb |= (a[i] - orc_model_margin) ^ (a[i] + orc_model_margin);
         inside = inside && (a[i] >> 23) == 127u;
     }
     const int depth_off = 23 - (int)depth;
@@ -172,7 +175,7 @@ static void model_cast(const orc_lnode *raw, uint32_t depth, const float org[3],
         const uint32_t ob[3] = { f2u(px), f2u(py), f2u(pz) };
         const uint32_t hb[3] = { f2u(prev_pos[0]), f2u(prev_pos[1]), f2u(prev_pos[2]) };
         uint32_t db = 0u, mb = 0u;
-        for (int i = 0; i < 3; i++) { db |= ob[i] ^ hb[i]; mb |= (ob[i] - ORC_MARGIN) ^ (ob[i] + ORC_MARGIN); }
+        for (int i = 0; i < 3; i++) { db |= ob[i] ^ hb[i]; mb |= (ob[i] - orc_model_margin) ^ (ob[i] + orc_model_margin); }
         int s0 = highbit(db | (mb + mb));
         if (s0 < (int)prev->scale) s0 = (int)prev->scale;
         if (s0 < 22) {

@@ -42,6 +42,8 @@ int main(int argc, char** argv)
     const uint32_t spp = (uint32_t)std::atoi(argv[5]), frames = (uint32_t)std::atoi(argv[6]);
     const uint32_t F = 3, ROW_BLOCK = 8;
     if (world < 1 || world > 8) return 2;
+    const int die_rank = std::getenv("PW_DIE_RANK") ? std::atoi(std::getenv("PW_DIE_RANK")) : -1;
+    const int die_frame = std::getenv("PW_DIE_AT_FRAME") ? std::atoi(std::getenv("PW_DIE_AT_FRAME")) : -1;
 
     // ---- ranks: fork BEFORE the first HIP call; one pipe from rank 0 to every other rank carries the set-up message
     int rank = 0;
@@ -111,6 +113,7 @@ int main(int argc, char** argv)
             void* st = pipe.stream(slot);
             if (rank != 0 && i >= F)                            // rank 0 has consumed the frame this framebuffer holds
                 vrc_host::check(vrc_stream_wait_flag(flags, consumed(slot), i - F + 1, st), "wait consumed");
+            if (die_rank == rank && die_frame == (int)i) _exit(5);      // the failure test: vanish with frames in flight, flags unwritten
             pipe.submit(cam);
             if (rank != 0) {
                 vrc_host::check(vrc_stream_write_flag(flags, written(slot, rank), i + 1, st), "write written");
@@ -120,7 +123,11 @@ int main(int argc, char** argv)
                 vrc_host::check(vrc_stream_write_flag(flags, consumed(slot), i + 1, st), "write consumed");
             }
         }
-        pipe.waitAll();
+        // the watchdog instead of a blind synchronize: rank 0 watches its children, a child its parent and its siblings
+        std::vector<int32_t> peer_pids;
+        if (rank == 0) for (pid_t k : kids) peer_pids.push_back((int32_t)k);
+        else { peer_pids.push_back((int32_t)getppid()); for (pid_t k : kids) peer_pids.push_back((int32_t)k); }
+        pipe.waitAllWatched(flags, peer_pids, 60000);
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 
         if (rank == 0) {
@@ -150,6 +157,8 @@ int main(int argc, char** argv)
     } catch (const std::exception& e) {
         std::fprintf(stderr, "rank %d: %s\n", rank, e.what());
         rc = 6;
+        if (rank == 0) for (pid_t k : kids) { int status; (void)waitpid(k, &status, 0); }     // their watchdogs end them too
+        _exit(rc);                                          // (no destructors: they would synchronise streams of a dead exchange)
     }
     if (rank != 0) _exit(rc);
     return rc;

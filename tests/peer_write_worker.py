@@ -59,6 +59,8 @@ def main():
         rc, ts = rcs[i % in_flight], streams[i % in_flight]
         with torch.cuda.stream(ts):
             dbg("frame", i, "before_render")
+            if rank == int(os.environ.get("PW_DIE_RANK", "-1")) and i == int(os.environ.get("PW_DIE_AT_FRAME", "-1")):
+                os._exit(5)             # the failure test: this rank vanishes with frames in flight and flags unwritten
             peers.before_render(i, ts.cuda_stream)
             rc.frame_index = i * spp
             rc.renderFrameResolved(cam, spp=spp, stream=ts.cuda_stream, row_block=vd.ROW_BLOCK, shard_index=rank, shard_count=world)
@@ -70,6 +72,11 @@ def main():
                 keep[i].copy_(fb[i % in_flight], non_blocking=True)
             peers.consumed_on(i, ts.cuda_stream)
     dbg("all frames enqueued")
+    try:
+        peers.wait([ts.cuda_stream for ts in streams], timeout_s=float(os.environ.get("PW_TIMEOUT_S", "60")))   # never a blind synchronize
+    except vrc.capi.VrcError as e:
+        print(json.dumps({"rank": rank, "error": str(e)}), flush=True)
+        os._exit(7)                     # no collective clean-up with a dead peer: leave at once, non-zero
     torch.cuda.synchronize()
     dbg("synchronized")
     dt = time.perf_counter() - t0

@@ -83,3 +83,57 @@ def test_cpp_host_peer_writes(built, tmp_path, world):
     os.makedirs(log, exist_ok=True)
     with open(os.path.join(log, f"cpp_peer_write_world{world}.json.log"), "w") as f:
         f.write(json.dumps(d) + "\n")
+
+
+def test_a_dead_writer_ends_the_run_instead_of_hanging_it(built):
+    """a stream-ordered flag wait has no timeout.  Rank 1 of 3 vanishes before its fifth frame, flags unwritten,
+    with frames in flight on every rank: the watchdog (vrc_ipc_stream_wait via PeerFrames.wait) must notice the dead process,
+    release every wait in every process and end the other ranks non-zero within seconds -- not at the test's kill timeout."""
+    import time
+    port = _free_port()
+    procs = []
+    t0 = time.monotonic()
+    for rank in range(3):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="3", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   PW_DIE_RANK="1", PW_DIE_AT_FRAME="4", PW_FRAMES="12", PW_TIMEOUT_S="120")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "peer_write_worker.py")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=90)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise AssertionError("the surviving ranks hung on the dead writer's flag")
+        outs.append((p.returncode, o, e))
+    assert [rc for rc, _, _ in outs] == [7, 5, 7], [(rc, e[-500:]) for rc, _, e in outs]
+    for k in (0, 2):
+        d = json.loads([ln for ln in outs[k][1].splitlines() if ln.startswith("{")][-1])
+        assert "vrc error -5" in d["error"], d                       # VRC_ERR_PEER, with the reason
+    assert time.monotonic() - t0 < 80
+    log = os.path.join(ROOT, "gpurun_out", "r04")
+    os.makedirs(log, exist_ok=True)
+    with open(os.path.join(log, "peer_write_dead_writer.json.log"), "w") as f:
+        f.write(json.dumps({"exit_codes": [rc for rc, _, _ in outs], "seconds": round(time.monotonic() - t0, 1),
+                            "rank0": outs[0][1].strip().splitlines()[-1]}) + "\n")
+
+
+def test_cpp_host_dead_writer(built, tmp_path):
+    """the same failure from the C++ host (HipFramePipeline::waitAllWatched): a forked rank _exit()s mid-run"""
+    exe = str(tmp_path / "peer_write_main")
+    libdir = os.path.join(ROOT, "cpuvoxelraycaster_amd")
+    subprocess.check_call(["g++", "-std=c++14", "-O1", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                           os.path.join(ROOT, "tests", "cpp", "peer_write_main.cpp"), "-o", exe,
+                           "-L" + libdir, "-l:libvrc_hip.so", "-L/opt/rocm/lib", "-lamdhip64", "-lpthread",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    data = os.path.join(libdir, "data")
+    p = subprocess.Popen([exe, "3", "8", "1280", "720", "4", "12", os.path.join(data, "grass_top_16x16.rgb"), os.path.join(data, "grass_side_16x16.rgb")],
+                         env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PW_DIE_RANK="2", PW_DIE_AT_FRAME="5"),
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        out, err = p.communicate(timeout=90)
+    except subprocess.TimeoutExpired:
+        os.killpg(p.pid, 9)
+        raise AssertionError("peer_write_main hung on the dead writer's flag")
+    assert p.returncode == 6 and "vrc_ipc_stream_wait" in err, (p.returncode, err[-800:])

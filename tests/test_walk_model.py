@@ -217,3 +217,71 @@ def test_camera_rays_start_on_the_camera_path(depth):
         mod_s, _, _ = model_cast(L, nodes, depth, so, sd, 0.0, stP, P["position"])
         assert same(ref_s, mod_s), (k, pos)
     assert all(t > 0 for t in total_skipped)
+
+
+def _adversary_rays(nodes, depth, L, n_hits, rng, light, cam_rays):
+    """primary hits -> origins k ulps either side of the planes of every scale -> directions (tests/adversaries.py)"""
+    import adversaries as A
+    org, dir_ = cam_rays
+    ref = O.cast_rays(nodes, depth, org, dir_, 0.0, 0.0, threads=8)
+    mod, st, _ = model_cast(L, nodes, depth, org, dir_, 0.0)
+    assert same(ref, mod)
+    hit = np.flatnonzero(ref["hit"] != 0)
+    hit = hit[rng.permutation(len(hit))[:n_hits]]
+    P, stP = ref[hit], np.ascontiguousarray(st[hit])
+    o, owner, meta = A.origins_near_planes(P["position"], depth)
+    d, oi = A.directions(o, light, rng)
+    return o[oi], d, np.ascontiguousarray(stP[owner[oi]]), np.ascontiguousarray(P["position"][owner[oi]]), meta[oi]
+
+
+def test_constructed_margin_adversaries():
+    """Round-3 verdict item 6: origins constructed k = 0..16 ulps either side of a plane of EVERY scale the tree has, on one, two
+    and three axes, x 8 mirror masks x directions with components at +-2^-23 and +-0, with and without the LOD coefficient.  The
+    model (= the kernel's formulation) must equal the oracle at the shipped margin of 8 ulps; run at margins 0..8 it records where
+    the start below the root first holds -- the error analysis says above 4.5 ulps."""
+    import cpuvoxelraycaster_amd as vrc
+    L = model_lib()
+    margin = C.c_uint32.in_dll(L, "orc_model_margin")
+    assert margin.value == 8
+    rng = np.random.default_rng(2024)
+    f = np.float32
+    scenes = []
+    depth = 9
+    nodes = vrc.build_terrain_lsvo(O.load_terrain_heights(), depth)
+    scenes.append((nodes, depth, camera_rays(4000, depth, rng, -0.6), 24, np.asarray(vrc.reference_light(depth), f)))
+    # leaves and empty space at every level: blobs + noise at 64^3 through the oracle's builder
+    depth = 6
+    S0 = 1 << depth
+    g = np.indices((S0, S0, S0)).astype(np.float32)
+    vol = rng.random((S0, S0, S0)) < 0.02
+    for _ in range(5):
+        c, r = rng.uniform(0, S0, 3), rng.uniform(3, S0 / 3)
+        vol |= ((g[0] - c[0]) ** 2 + (g[1] - c[1]) ** 2 + (g[2] - c[2]) ** 2) < r * r
+    nodes6 = O.compile_voxels(depth, np.argwhere(vol).astype(np.int64))
+    org6 = rng.uniform(1.05, 1.95, (4000, 3)).astype(f)
+    scenes.append((nodes6, depth, (org6, normalize(rng.normal(size=(4000, 3)))), 24, np.asarray([1.3, 1.9, 1.6], f)))
+    bad = np.zeros(9, np.int64)
+    total = skipped_at_8 = 0
+    try:
+        for nodes, depth, cam_rays, n_hits, light in scenes:
+            o, d, stP, pp, meta = _adversary_rays(nodes, depth, L, n_hits, rng, light, cam_rays)
+            for coef in (0.0, 0.5):
+                ref = O.cast_rays(nodes, depth, o, d, coef, 0.0, threads=8)
+                total += len(o)
+                for m in range(9):
+                    margin.value = m
+                    mod, _, sk = model_cast(L, nodes, depth, o, d, coef, stP, pp)
+                    differ = (mod.view(np.uint8).reshape(len(o), -1) != ref.view(np.uint8).reshape(len(o), -1)).any(axis=1)
+                    bad[m] += int(differ.sum())
+                    if m == 8:
+                        skipped_at_8 += int(sk.sum())
+                        assert (sk > 0).mean() > 0.5                                     # most of these rays DO start below the root
+    finally:
+        margin.value = 8
+    print(f"{total} constructed rays; rays that differ from the oracle by margin 0..8: {bad.tolist()}")
+    assert bad[8] == 0 and skipped_at_8 > 0
+    assert bad[0] > 0 and bad[1] > 0                       # the construction bites: without a margin the walk goes wrong
+    first_ok = next(m for m in range(9) if not bad[m:].any())
+    # measured (6.65 M rays): [188963, 42174, 352, 0, 0, 0, 0, 0, 0] differ at margins 0..8 -- the walk first holds at 3 ulps, below
+    # the 4.5 of the hand-derived bound; the shipped 8 keeps 5 ulps of slack over what these adversaries need (DESIGN.md section 4)
+    assert first_ok <= 4, (first_ok, bad.tolist())

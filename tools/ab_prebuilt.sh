@@ -1,20 +1,14 @@
 #!/bin/bash
-# A/B of PREBUILT library variants (tools/build_variant.py -> gpurun_variants/var_<name>.so) on the GPU box: each is copied
-# over the package's libvrc_hip.so (stamped with the default flag line so that build.py does not rebuild it) and bench.py runs.
-#   usage: tools/ab_prebuilt.sh <outdir> "<bench args>" name1 name2 ...     (the product library is restored at the end)
+# A/B of PREBUILT library variants (tools/build_variant.py -> gpurun_variants/var_<name>.so) on the GPU box: bench.py runs with
+# VRC_LIB pointing at each (cpuvoxelraycaster_amd/capi.py loads it in the product's place and says so; the product library is
+# never touched; the bench line records the library in config.library).  The name `product` runs the product library.
+#   usage: tools/ab_prebuilt.sh <outdir> "<bench args>" name1 name2 ...
 OUT=$1; shift
 BARGS=$1; shift
-PKG=cpuvoxelraycaster_amd
 mkdir -p $OUT
-cp $PKG/libvrc_hip.so /tmp/libvrc_hip.product.so
 for name in "$@"; do
-  cp gpurun_variants/var_$name.so $PKG/libvrc_hip.so
-  python3 - <<'PY'
-from cpuvoxelraycaster_amd import build
-open(build.STAMP, "w").write(build._flag_line() + "\n")
-PY
-  touch $PKG/libvrc_hip.so
-  python3 bench.py --no-cpu-baseline --no-extras $BARGS > $OUT/$name.log 2>&1
+  if [ "$name" = product ]; then unset VRC_LIB; else export VRC_LIB=$(pwd)/gpurun_variants/var_$name.so; fi
+  python3 bench.py --no-cpu-baseline --no-extras $BARGS > $OUT/$name.log 2>$OUT/$name.err
   python3 - "$OUT/$name.log" "$name" <<'PY'
 import json, sys
 try:
@@ -24,4 +18,4 @@ except Exception as e:
     print(sys.argv[2], "FAILED", e)
 PY
 done
-cp /tmp/libvrc_hip.product.so $PKG/libvrc_hip.so; touch $PKG/libvrc_hip.so
+unset VRC_LIB

@@ -20,6 +20,7 @@ svo = vrc.LSVO.fromFastNoiseTerrain(depth, textures=vrc.load_textures())
 cam = vrc.reference_camera(depth, pitch=-0.5)
 L = vrc.capi.load()
 BLOCKS = int(os.environ.get("VRC_BLOCKS", "0"))
+LANE_SAMPLES = int(os.environ.get("VRC_LANE_SAMPLES", "0"))     # A/B of the lane <-> (pixel, sample) map (0 = the library's choice)
 
 
 def period(N, F, whole):
@@ -30,6 +31,8 @@ def period(N, F, whole):
         rc.use_gi, rc.use_samples, rc.shadow_samples = True, True, 1
         if whole:
             rc.setSampleChunk(spp)
+        if LANE_SAMPLES:
+            rc.setLaneSamples(LANE_SAMPLES)
         if BLOCKS:
             rc.setTuning(blocks_per_cu=BLOCKS)      # force the 6 / 7 / 8 waves-per-SIMD build (A/B of sync_waves_for's choice)
         rcs.append(rc)
