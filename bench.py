@@ -48,9 +48,6 @@ sys.path.insert(0, ROOT)
 # then share queues, and two frames "in flight" on one hardware queue run one after the other (measured: 1.35 instead of
 # 1.30 ms per frame with four frame streams).  Must be set before the HIP runtime starts.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-# the cpu_baseline leg's OpenMP teams: one thread per core, spread over the sockets, not migrated (read when libgomp starts)
-os.environ.setdefault("OMP_PROC_BIND", "spread")
-os.environ.setdefault("OMP_PLACES", "cores")
 
 CONFIGS = {
     # name: depth, width, height, spp, use_gi, aperture
@@ -225,7 +222,22 @@ def cpu_baseline(cfg, nodes, textures, cam, light, budget_s=3.5):
                     "frame_samples": n_sw, "seconds": round(dt_sw, 2), "dropped_executes_retried": sw.retries})
         sw.close()
     # OpenMP over a few thread counts: on a shared host more threads are not always faster -- the fastest is the headline
-    counts = sorted({c for c in (16, 32, 64, 128, usable) if c <= usable} or {usable})
+    # How many cores does this process really get?  The GPU boxes of this pool give a container a CFS quota
+    # (/sys/fs/cgroup/cpu.max, e.g. "1600000 100000" = 16 CPUs' worth of time per period) on a host with 256 hardware threads:
+    # os.sched_getaffinity() says 256, but a team of more threads than the quota only gets throttled -- which is why rounds 2-3
+    # saw the rate PEAK at 16 threads and fall to a third at 256 (round-3 verdict item 8).  So the team sizes tried are those
+    # around the quota, and each variant records the CPU seconds it got per wall second.  (Pinning threads -- OMP_PROC_BIND /
+    # OMP_PLACES -- does not help under a quota, and binds the main thread to one core, which then is all that
+    # sched_getaffinity() and the reference's swarm pool see: measured, 8.8 instead of 60 Mrays/s.)
+    quota_cores = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            q, per = fh.read().split()[:2]
+            quota_cores = None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    cap = usable if not quota_cores else min(usable, max(1, int(round(quota_cores))))
+    counts = sorted({c for c in (cap // 2, cap, 2 * cap, 4 * cap) if 1 <= c <= usable} or {usable})
     best = None
     for c in counts:
         r, n, dt = run("omp", c)
@@ -241,7 +253,9 @@ def cpu_baseline(cfg, nodes, textures, cam, light, budget_s=3.5):
                     "parity": False, "value": round(r2 / dt2 / 1e6, 3), "frame_samples": n2, "seconds": round(dt2, 2)})
     # what the host gives this process: a cgroup CPU quota and the other tenants of the box decide how many of the `usable`
     # cores a thread team really gets -- cpu_seconds_per_second of a variant is the number of cores it was running on
-    host = {"os_cpu_count": os.cpu_count(), "usable": usable}
+    host = {"os_cpu_count": os.cpu_count(), "usable": usable, "cgroup_quota_cores": quota_cores,
+            "scaling_note": ("the rate peaks at the container's CPU quota and falls beyond it (threads over the quota are throttled, not run): "
+                             "cpu_seconds_per_second of each variant is the number of cores it actually ran on") if quota_cores else None}
     for name, path in (("cgroup_cpu_max", "/sys/fs/cgroup/cpu.max"), ("loadavg", "/proc/loadavg")):
         try:
             with open(path) as fh:
@@ -377,9 +391,7 @@ def main():
                     help="lane <-> (pixel, sample) map of the frame kernel (vrc_renderer_set_lane_samples): 1 = 8 x 8 pixels per wave, "
                          "4 = 4 x 4 pixels x 4 samples abreast, 0 = the library's choice")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra measurements (2-bounce extension)")
-    ap.add_argument("--tuning", default="", help="blocks_per_cu,refill_threshold,chunk")
-    ap.add_argument("--kernel", type=int, default=2,
-                    help="frame kernel: 2 stage-synchronous per tile (default), 0 tile-phased with LDS job pool, 1 persistent mixed-stage")
+    ap.add_argument("--tuning", default="", help="blocks_per_cu: workgroups of the frame kernel per CU (= which waves-per-SIMD build), 0 = the library's choice")
     args = ap.parse_args()
 
     # the fork/join of main.cpp:139-154 across GPUs: plain `python bench.py --gpus N` starts its own ranks -- decided here,
@@ -435,8 +447,7 @@ def main():
     else:
         g.build()
     if args.tuning:
-        vrc.capi.check(vrc.capi.load().vrc_set_tuning(*[int(v) for v in args.tuning.split(",")]))
-    vrc.capi.check(vrc.capi.load().vrc_set_kernel(args.kernel))
+        vrc.capi.check(vrc.capi.load().vrc_set_tuning(int(args.tuning.split(",")[0])))
 
     cfg = CONFIGS[args.config]
     depth, W, H, spp = cfg["depth"], cfg["width"], cfg["height"], cfg["spp"]
@@ -797,7 +808,7 @@ def main():
                     "(oracle/vrc_oracle.c global_illumination, level 1); same frame, same frames in flight and unit policy as the timed "
                     "region, measured right after it"}
 
-    if rank == 0 and world == 1 and not dist_on and not args.no_extras and args.kernel == 2 and cfg["aperture"] == 0.0 and cfg.get("gi_bounces", 1) <= 1:
+    if rank == 0 and world == 1 and not dist_on and not args.no_extras and cfg["aperture"] == 0.0 and cfg.get("gi_bounces", 1) <= 1:
         # untimed extra, the other way round: the same frames with every ray started at the root as the reference's loop does
         # (vrc_renderer_set_walk_from_root) instead of below it, next to the previous hit / the camera -- what the start below
         # the root is worth; same image, same rays, same sum of complexities
@@ -830,7 +841,7 @@ def main():
             "note": "measurement switch (vrc_renderer_set_walk_from_root): no ray starts below the root; same image, rays and "
                     "complexity sums as the timed region, same frames in flight and unit policy, measured right after it"}
 
-    if rank == 0 and world == 1 and not dist_on and not args.no_extras and cfg["aperture"] == 0.0 and args.kernel == 2:
+    if rank == 0 and world == 1 and not dist_on and not args.no_extras and cfg["aperture"] == 0.0:
         # untimed extra, beyond the reference: the same frames with vrc_renderer_set_invariant_ray_reuse -- a pinhole camera's
         # primary ray and the shadow ray of its hit are the same for every sample, the reference (and `value`) walk them
         # once per sample, here once per pixel and frame.  Same image bit for bit (tests/test_gpu_reuse.py); its Mrays/s
@@ -880,7 +891,7 @@ def main():
         # passes recorded in profiles/traffic.json -- only when that record was taken on THIS tree's kernel sources
         # (the stage-synchronous kernel has a specialisation for the pinhole camera, see csrc/vrc_kernels.hip launch_render)
         sync_kernel_name = rcs[0].lastKernel()       # the build the library chose for this kind of launch (vrc_renderer_last_kernel)
-        rec, why = pmc_record(f"{args.config}_n{world}" + ("" if F > 1 else "_inflight1"), kernel=sync_kernel_name, fused=fused, inflight=F) if args.kernel == 2 else (None, "PMC record exists for k_render_sync only")
+        rec, why = pmc_record(f"{args.config}_n{world}" + ("" if F > 1 else "_inflight1"), kernel=sync_kernel_name, fused=fused, inflight=F)
         traffic = rec["traffic_bytes"] if rec else None
         roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
@@ -926,7 +937,7 @@ def main():
             issue["floor_note"] = (f"profiles/issue_model.json was made from kernel sources {model.get('source_hash')}, this tree's are "
                                    f"{kernel_source_hash()}: re-run tools/issue_model.py")
             model = None
-        walks_model = model is not None and args.config == "c3" and abs(args.pitch + 0.5) < 1e-9 and args.kernel == 2
+        walks_model = model is not None and args.config == "c3" and abs(args.pitch + 0.5) < 1e-9
         if model is not None and not walks_model:
             issue["floor_note"] = ("block issue frequencies of the walk exist for the c3 workload at pitch -0.5 only (tests/tools/path_schedule.py "
                                    "--dump): the slow-class resource is left out of this floor")

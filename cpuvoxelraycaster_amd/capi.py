@@ -88,8 +88,7 @@ SYMBOLS = {
     "vrc_resolve_shard": (_int, [_vp, _u32, _u32, _u32, _vp, _int, _vp]),
     "vrc_unpack_shards": (_int, [_vp, _u32, _u32, _u32, _u32, _vp, _vp]),
     "vrc_make_rotation": (None, [_f32, _f32, _vp]),
-    "vrc_set_tuning": (_int, [_u32, _u32, _u32]),
-    "vrc_set_kernel": (_int, [_u32]),
+    "vrc_set_tuning": (_int, [_u32]),
     "vrc_presenter_create": (_int, [_int, _u32, _u32, _u32, _u32, C.POINTER(_vp)]),
     "vrc_presenter_destroy": (_int, [_vp]),
     "vrc_present": (_int, [_vp, _vp, _f32, _u32, _vp]),
@@ -100,12 +99,12 @@ SYMBOLS = {
     "vrc_presenter_read": (_int, [_vp, _vp, _vp, _vp]),
     "vrc_selftest_exact_arith": (_int, [_int, _vp]),
     "vrc_set_sample_chunk": (_int, [_u32]),
-    "vrc_renderer_set_tuning": (_int, [_vp, _u32, _u32, _u32]),
-    "vrc_renderer_set_kernel": (_int, [_vp, _u32]),
+    "vrc_renderer_set_tuning": (_int, [_vp, _u32]),
     "vrc_renderer_set_sample_chunk": (_int, [_vp, _u32]),
     "vrc_renderer_set_invariant_ray_reuse": (_int, [_vp, _u32]),
     "vrc_renderer_set_walk_from_root": (_int, [_vp, _u32]),
     "vrc_renderer_set_lane_samples": (_int, [_vp, _u32]),
+    "vrc_set_lane_samples": (_int, [_u32]),
     "vrc_renderer_last_kernel": (C.c_char_p, [_vp]),
     "vrc_ipc_export_image": (_int, [_vp, _vp]),
     "vrc_ipc_open_image": (_int, [_int, _vp, C.POINTER(_vp)]),
@@ -114,6 +113,7 @@ SYMBOLS = {
     "vrc_ipc_flags_open": (_int, [C.c_char_p, _u32, _int, _int, C.POINTER(_vp)]),
     "vrc_ipc_flags_close": (_int, [_vp]),
     "vrc_ipc_stream_wait": (_int, [_vp, _vp, _vp, _u32, _u32]),
+    "vrc_ipc_flag_set": (_int, [_vp, _u32, _u32]),
     "vrc_stream_write_flag": (_int, [_vp, _u32, _u32, _vp]),
     "vrc_stream_wait_flag": (_int, [_vp, _u32, _u32, _vp]),
     "vrc_ipc_flag_value": (_u32, [_vp, _u32]),

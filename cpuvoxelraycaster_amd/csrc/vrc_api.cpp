@@ -52,10 +52,7 @@ namespace {
 // kernels, from different threads); the process-wide defaults below only seed new renderers and are read and written
 // under g_tuning_mu.
 struct Tuning {
-    uint32_t blocks_per_cu = 4;
-    uint32_t refill_threshold = 32;
-    uint32_t chunk = 64;
-    uint32_t kernel = VRC_KERNEL_SYNC;
+    uint32_t blocks_per_cu = 0;         // 0 = the library's choice of build (waves per SIMD), see sync_waves_for
     bool blocks_per_cu_set = false;
     uint32_t sample_chunk = 0;   // 0 = automatic
     uint32_t tail_units_per_wave = 4;   // automatic chunking: units of half the chunk for the last tiles (0 = off); tools/chunk_time.py
@@ -67,9 +64,6 @@ Tuning g_tuning;
 std::mutex g_tuning_mu;
 
 constexpr uint32_t VRC_MAX_SPP = 65536;          // per call; the u32 accumulators hold 255 * 16.8 M samples in total
-// queue chunk of k_render: the head counter overshoots n_items by at most (waves in flight) x chunk after the queue runs dry;
-// 8192 waves x 2^16 + 2^31 pixels stays below 2^32
-constexpr uint32_t VRC_MAX_QUEUE_CHUNK = 1u << 16;
 
 int apply_sample_chunk(Tuning& t, uint32_t samples_per_unit)
 {
@@ -79,19 +73,11 @@ int apply_sample_chunk(Tuning& t, uint32_t samples_per_unit)
     t.sample_chunk = samples_per_unit;
     return VRC_OK;
 }
-int apply_kernel(Tuning& t, uint32_t kernel)
+int apply_tuning(Tuning& t, uint32_t blocks_per_cu)
 {
-    if (kernel > VRC_KERNEL_SYNC) return vrc::fail(VRC_ERR_INVALID, "unknown frame kernel %u", kernel);
-    t.kernel = kernel;
-    return VRC_OK;
-}
-int apply_tuning(Tuning& t, uint32_t blocks_per_cu, uint32_t refill_threshold, uint32_t chunk)
-{
-    if (blocks_per_cu > 8 || refill_threshold > 64 || chunk > VRC_MAX_QUEUE_CHUNK) return vrc::fail(VRC_ERR_INVALID, "tuning out of range");
-    t.blocks_per_cu = blocks_per_cu ? blocks_per_cu : 4;
+    if (blocks_per_cu > 8) return vrc::fail(VRC_ERR_INVALID, "vrc_set_tuning: blocks_per_cu %u > 8", blocks_per_cu);
+    t.blocks_per_cu = blocks_per_cu;
     t.blocks_per_cu_set = blocks_per_cu != 0;
-    t.refill_threshold = refill_threshold ? refill_threshold : 32;
-    t.chunk = chunk ? chunk : 64;
     return VRC_OK;
 }
 
@@ -178,15 +164,10 @@ extern "C" int vrc_set_sample_chunk(uint32_t samples_per_unit)
     std::lock_guard<std::mutex> lk(g_tuning_mu);
     return apply_sample_chunk(g_tuning, samples_per_unit);
 }
-extern "C" int vrc_set_kernel(uint32_t kernel)
+extern "C" int vrc_set_tuning(uint32_t blocks_per_cu)
 {
     std::lock_guard<std::mutex> lk(g_tuning_mu);
-    return apply_kernel(g_tuning, kernel);
-}
-extern "C" int vrc_set_tuning(uint32_t blocks_per_cu, uint32_t refill_threshold, uint32_t chunk)
-{
-    std::lock_guard<std::mutex> lk(g_tuning_mu);
-    return apply_tuning(g_tuning, blocks_per_cu, refill_threshold, chunk);
+    return apply_tuning(g_tuning, blocks_per_cu);
 }
 extern "C" int vrc_renderer_set_sample_chunk(vrc_renderer* r, uint32_t samples_per_unit)
 {
@@ -207,6 +188,13 @@ extern "C" int vrc_renderer_set_walk_from_root(vrc_renderer* r, uint32_t on)
     r->tuning.walk_from_root = on != 0;
     return VRC_OK;
 }
+extern "C" int vrc_set_lane_samples(uint32_t samples)
+{
+    if (samples != 0 && samples != 1 && samples != 4) return fail(VRC_ERR_INVALID, "vrc_set_lane_samples: %u (0, 1 or 4)", samples);
+    std::lock_guard<std::mutex> lk(g_tuning_mu);
+    g_tuning.lane_samples = samples;
+    return VRC_OK;
+}
 extern "C" int vrc_renderer_set_lane_samples(vrc_renderer* r, uint32_t samples)
 {
     if (!r) return fail(VRC_ERR_INVALID, "null renderer");
@@ -215,15 +203,10 @@ extern "C" int vrc_renderer_set_lane_samples(vrc_renderer* r, uint32_t samples)
     return VRC_OK;
 }
 extern "C" const char* vrc_renderer_last_kernel(const vrc_renderer* r) { return r ? r->last_kernel : ""; }
-extern "C" int vrc_renderer_set_kernel(vrc_renderer* r, uint32_t kernel)
+extern "C" int vrc_renderer_set_tuning(vrc_renderer* r, uint32_t blocks_per_cu)
 {
     if (!r) return fail(VRC_ERR_INVALID, "null renderer");
-    return apply_kernel(r->tuning, kernel);
-}
-extern "C" int vrc_renderer_set_tuning(vrc_renderer* r, uint32_t blocks_per_cu, uint32_t refill_threshold, uint32_t chunk)
-{
-    if (!r) return fail(VRC_ERR_INVALID, "null renderer");
-    return apply_tuning(r->tuning, blocks_per_cu, refill_threshold, chunk);
+    return apply_tuning(r->tuning, blocks_per_cu);
 }
 
 // ---------------------------------------------------------------------------
@@ -561,7 +544,7 @@ extern "C" int vrc_render_frame_resolved(vrc_renderer* r, const vrc_camera* cam,
 {
     if (!r || !cam || !p) return fail(VRC_ERR_INVALID, "vrc_render_frame_resolved: null argument");
     if (!p->use_samples) return fail(VRC_ERR_INVALID, "vrc_render_frame_resolved: needs use_samples (there is nothing to resolve otherwise)");
-    if (r->tuning.kernel == VRC_KERNEL_SYNC && p->checker_parity < 0) return render_impl(r, cam, p, true, dst_dev, stream);
+    if (p->checker_parity < 0) return render_impl(r, cam, p, true, dst_dev, stream);
     int rc = render_impl(r, cam, p, false, nullptr, stream);
     if (rc) return rc;
     const bool sharded = p->row_block && p->shard_count > 1;
@@ -607,36 +590,36 @@ int render_impl(vrc_renderer* r, const vrc_camera* cam, const vrc_frame_params* 
         a.p.row_block = 0; a.p.shard_index = 0; a.p.shard_count = 1;
     }
     // checkerboard frames on the stage-synchronous kernel: 16 x 8 pixel tiles, 64 selected pixels each
-    a.checker_wide = (tuning.kernel == VRC_KERNEL_SYNC && p->checker_parity >= 0) ? 1u : 0u;
+    a.checker_wide = p->checker_parity >= 0 ? 1u : 0u;
     // the lane <-> (pixel, sample) map (vrc_renderer_set_lane_samples): four samples abreast where the kernel has a build for it
     // and the frame's samples divide by four -- the accumulators make the order of a pixel's samples immaterial, the 0.4 / 0.6
     // blend of the non-sample mode (raycaster.hpp:79-85) does not
-    const bool can_s4 = tuning.kernel == VRC_KERNEL_SYNC && a.p.use_samples && a.p.spp % 4u == 0u && p->checker_parity < 0 &&
+    const bool can_s4 = a.p.use_samples && a.p.spp % 4u == 0u && p->checker_parity < 0 &&
                         a.p.gi_bounces <= 1u && !tuning.walk_from_root && !tuning.reuse_invariant &&
                         (tuning.sample_chunk == 0u || tuning.sample_chunk % 4u == 0u);
-    a.lane_samples = (can_s4 && tuning.lane_samples != 1u) ? 4u : 1u;
+    // The library's choice (lane_samples 0), measured on C3 / C4 and their 1/2 .. 1/8 shards (profiles/r04/ab_lane_map.txt,
+    // shard_inflight_lane_map.txt): four abreast for a launch that has the chip to itself -- 3-6 % off a frame's latency: four
+    // times the units, a quarter as long, no accumulator atomics -- and the pixel tiles for whole-spp units, which a caller asks
+    // for when frames overlap (there the hoisted set-up of the 8 x 8 map wins by 5 %: both maps issue the same number of VALU
+    // instructions, profiles/r04/pmcq_ns{1,4}.txt).
+    const bool caller_whole_spp = tuning.sample_chunk != 0u && tuning.sample_chunk >= a.p.spp;
+    a.lane_samples = (can_s4 && (tuning.lane_samples == 4u || (tuning.lane_samples == 0u && !caller_whole_spp))) ? 4u : 1u;
     const uint32_t tw = a.lane_samples == 4u ? 4u : 8u;
     const uint32_t tiles_per_row = a.checker_wide ? (r->width + 15u) / 16u : (r->width + tw - 1u) / tw;
     const uint64_t items = (uint64_t)tiles_per_row * ((rows + tw - 1u) / tw) * 64ull;
     if (items > 0xfffffff0ull) return fail(VRC_ERR_INVALID, "vrc_render_frame: frame too large");
     a.n_items = (uint32_t)items;
-    a.chunk = tuning.chunk;
-    a.refill_threshold = tuning.refill_threshold;
     if (a.n_items == 0) return VRC_OK;
     int queue_used = -1;
     {
         uint32_t* sets[2] = {a.queue, a.queue + vrc::VRC_QUEUE_BYTES / 4};
-        if (tuning.kernel == VRC_KERNEL_SYNC) {
-            // take a set that is known to be zero (memset one if neither is: first use after another kernel); the launch
-            // zeroes the other set, so the next launch finds its queue ready without a memset or a kernel in between
-            const int use = r->queue_zero[0] ? 0 : (r->queue_zero[1] ? 1 : 0);
-            if (!r->queue_zero[use]) HIP_TRY(hipMemsetAsync(sets[use], 0, vrc::VRC_QUEUE_BYTES, st));
-            a.queue = sets[use];
-            a.queue_other = sets[1 - use];
-            queue_used = use;
-        } else {
-            if (!r->queue_zero[0]) HIP_TRY(hipMemsetAsync(sets[0], 0, vrc::VRC_QUEUE_BYTES, st));
-        }
+        // take a set that is known to be zero (memset one if neither is: after an error exit); the launch zeroes the other
+        // set, so the next launch finds its queue ready without a memset or a kernel in between
+        const int use = r->queue_zero[0] ? 0 : (r->queue_zero[1] ? 1 : 0);
+        if (!r->queue_zero[use]) HIP_TRY(hipMemsetAsync(sets[use], 0, vrc::VRC_QUEUE_BYTES, st));
+        a.queue = sets[use];
+        a.queue_other = sets[1 - use];
+        queue_used = use;
         // Until the launch is known to have been enqueued neither set counts as zero: the other set is only zeroed BY this
         // launch (its block 0), so an error exit below must not leave it marked ready -- the next frame would take heads that
         // still hold the previous frame's consumed counts, render nothing and resolve a stale image.
@@ -648,15 +631,8 @@ int render_impl(vrc_renderer* r, const vrc_camera* cam, const vrc_frame_params* 
     a.tile_done = r->d_tile_done;
     a.resolve_dst = (uint32_t*)dst;
     uint64_t want = (items + VRC_RENDER_BLOCK - 1) / VRC_RENDER_BLOCK;
-    // k_render_tile: depth * 1 KiB of stacks + 21 KiB of job pools + 1.5 KiB of tables per workgroup
-    // (38.5 KiB at depth 9): at most 4 fit a CU's 160 KiB; 120 VGPRs allow 4 waves per SIMD as well
-    uint32_t bpc = tuning.blocks_per_cu;
-    if (tuning.kernel == VRC_KERNEL_TILE) {
-        const uint32_t lds = s->depth * 1024u + 4u * vrc::tile_wave_lds_bytes() + 1536u;
-        const uint32_t fit = 163840u / lds;
-        if (bpc > fit) bpc = fit;
-        if (bpc > vrc::tile_max_blocks_per_cu()) bpc = vrc::tile_max_blocks_per_cu();
-    } else if (tuning.kernel == VRC_KERNEL_SYNC) {
+    uint32_t bpc = 0;
+    {
         const uint32_t lds = 2u * s->depth * 1024u + 1536u + 128u + 544u + 32u;  // two stacks (primary path, secondary walks), tables, counters, camera paths
         const uint32_t fit = 163840u / lds;
         // which build of the kernel (waves per SIMD = workgroups per CU): by the kind of launch, or the caller's choice
@@ -672,7 +648,7 @@ int render_impl(vrc_renderer* r, const vrc_camera* cam, const vrc_frame_params* 
     }
     const uint64_t cap = (uint64_t)s->cu_count * bpc;
     a.sample_chunk = 0;
-    if (tuning.kernel == VRC_KERNEL_SYNC && a.p.use_samples && a.p.spp > 1) {
+    if (a.p.use_samples && a.p.spp > 1) {
         // Units should be short against the launch (its end waits for the last unit of every wave, and the oldest
         // wave of a SIMD runs ~3.6x faster than the youngest) yet not so small that the accumulator atomics and
         // queue traffic show: the largest chunk that still gives ~48 units per wave of a full grid, else 2 samples
@@ -706,7 +682,7 @@ int render_impl(vrc_renderer* r, const vrc_camera* cam, const vrc_frame_params* 
         want = (units + VRC_RENDER_BLOCK / 64 - 1) / (VRC_RENDER_BLOCK / 64);
     }
     const uint32_t grid = (uint32_t)(want < cap ? want : cap);
-    HIP_TRY(vrc::launch_render(a, grid, (int)tuning.kernel, st, &r->last_kernel));
+    HIP_TRY(vrc::launch_render(a, grid, st, &r->last_kernel));
     if (queue_used >= 0) r->queue_zero[1 - queue_used] = true;           // zeroed by the launch that is now in the stream
     return VRC_OK;
 }
@@ -947,6 +923,13 @@ extern "C" int vrc_stream_wait_flag(vrc_ipc_flags* f, uint32_t index, uint32_t v
     if (flags_given_up(f)) return fail(VRC_ERR_PEER, "vrc_stream_wait_flag: the exchange on %s was given up", f->name);
     HIP_TRY(hipSetDevice(f->device));
     HIP_TRY(hipStreamWaitValue32((hipStream_t)stream, f->dev + index, value, hipStreamWaitValueGte, 0xffffffffu));
+    return VRC_OK;
+}
+
+extern "C" int vrc_ipc_flag_set(vrc_ipc_flags* f, uint32_t index, uint32_t value)
+{
+    if (!f || index >= f->count) return fail(VRC_ERR_INVALID, "vrc_ipc_flag_set: bad argument");
+    __atomic_store_n(f->host + index, value, __ATOMIC_RELEASE);
     return VRC_OK;
 }
 

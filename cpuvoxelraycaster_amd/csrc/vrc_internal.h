@@ -9,9 +9,6 @@
 #include "../../include/vrc.h"
 
 #define VRC_RENDER_BLOCK 256
-#define VRC_KERNEL_TILE 0    // k_render_tile: tile-phased (default)
-#define VRC_KERNEL_MIXED 1   // k_render: persistent threads, mixed stages
-#define VRC_KERNEL_SYNC 2    // k_render_sync: stage-synchronous per tile
 
 // opaque handles of include/vrc.h
 struct vrc_scene {
@@ -43,7 +40,7 @@ constexpr uint32_t VRC_QUEUE_STRIDE = 1024;    // u32 between heads (4 KiB: sepa
 constexpr uint32_t VRC_STATS_BYTES = VRC_STAT_SLOTS * 64u;
 constexpr uint32_t VRC_QUEUE_BYTES = VRC_QUEUE_HEADS * VRC_QUEUE_STRIDE * 4u;   // one set of heads; a renderer has two
 
-// by-value kernel argument of k_render
+// by-value kernel argument of the frame kernels (k_render_sync*)
 struct FrameArgs {
     const uint2* nodes;       // LNode[] (8 B each)
     const uint8_t* tex;       // 1536 B: top table then side table
@@ -53,10 +50,8 @@ struct FrameArgs {
     uint64_t* stats;          // VRC_STAT_SLOTS x {rays, sum_complexity, primary_hits, pixels, iterations not executed, -, -, -}; summed by vrc_get_stats
     uint32_t* queue;          // work-queue heads, VRC_QUEUE_STRIDE u32 apart
     uint32_t depth, width, height;
-    uint32_t n_items;         // work items (8x8-tile order over this shard's rows)
-    uint32_t chunk;           // items a wave takes from the queue at once
-    uint32_t refill_threshold;// leave the traversal loop once this many lanes wait
-    uint32_t sample_chunk;    // k_render_sync: samples per work unit (0 = all spp in one unit)
+    uint32_t n_items;         // 64 x the tiles of this shard's rows (a tile = the pixels of one wave)
+    uint32_t sample_chunk;    // samples per work unit (0 = all spp in one unit)
     uint32_t sample_chunk_tail, tail_tiles;   // ... and for the last `tail_tiles` tiles (0 = same chunk)
     uint32_t checker_wide;    // k_render_sync, checkerboard frames: tiles are 16 x 8 pixels, every lane takes a selected pixel
     // k_render_sync*: the heads of the renderer's OTHER queue set, zeroed by this launch for the next one (the two sets
@@ -88,9 +83,7 @@ hipError_t launch_cast_ray_chains(const void* nodes, int depth, uint64_t n, cons
                                   const float* dir_b, float coef_b, vrc_hit* out_a, vrc_hit* out_b, uint32_t* not_executed, hipStream_t st);
 hipError_t launch_grid_cast(const uint8_t* cells, int X, int Y, int Z, uint64_t n, const float* org, const float* dir,
                             vrc_hit* out, hipStream_t st);
-uint32_t tile_wave_lds_bytes();       // LDS job pool per wave of k_render_tile
-uint32_t tile_max_blocks_per_cu();    // register-limited workgroups per CU of k_render_tile
-uint32_t sync_max_blocks_per_cu();    // ... of k_render_sync
+uint32_t sync_max_blocks_per_cu();    // register-limited workgroups per CU of k_render_sync
 uint32_t sync_s4_waves(bool pinhole); // waves per SIMD the samples-abreast builds were compiled for
 // The stage-synchronous kernels are built for 6 waves per SIMD (80 VGPRs), the lens one-bounce kernel also for 7 (72).
 // Rounds 2 and 3 shipped 7- and 8-wave builds of the pinhole kernels too, picked by a table (profiles/r03/sweep_waves.txt:
@@ -106,7 +99,7 @@ uint32_t sync_s4_waves(bool pinhole); // waves per SIMD the samples-abreast buil
 // kernel 7 with whole-spp units; a caller's vrc_renderer_set_tuning(blocks_per_cu) >= 7 selects the lens kernel's 7-wave build.
 uint32_t sync_waves_for(bool pinhole, bool one_bounce, bool use_gi, bool whole_spp_units, uint64_t pixel_samples, uint32_t requested);
 bool camera_is_pinhole(const vrc_camera& cam);   // the host's predicate for the pinhole kernels (see launch_render)
-hipError_t launch_render(const FrameArgs& a, uint32_t grid_blocks, int kernel, hipStream_t st, const char** launched);
+hipError_t launch_render(const FrameArgs& a, uint32_t grid_blocks, hipStream_t st, const char** launched);
 hipError_t launch_resolve(const void* accum, void* image, uint32_t n, hipStream_t st);
 hipError_t launch_fill_u32(void* p, uint32_t value, uint64_t n, hipStream_t st);
 hipError_t launch_sanitize_nodes(void* nodes, uint64_t n, hipStream_t st);   // leaf_mask &= child_mask

@@ -2,17 +2,18 @@
 // voxel ray-traversal hot path, plus their launchers.
 //
 //   k_cast_rays(_nolod)  T1   batch LSVO<N>::castRay (lsvo.hpp:33-172), one lane per ray
-//   k_render_sync   R0 + S1..S4  frame kernel (default): a wave owns an 8x8 pixel tile and runs each
-//                   stage of a sample -- primary, shadow, GI, GI shadow -- for all 64 lanes together
-//   k_render_tile   same frame, scheduler 0: lockstep primary/shadow, then the GI rays from a per-wave
-//                   LDS job pool filled by wave ballot / prefix-sum (mbcnt) compaction
-//   k_render        same frame, scheduler 1: persistent threads, every lane runs the whole
-//                   primary -> shadow -> GI -> GI-shadow state machine over ONE shared traversal loop
-//                   and is refilled from a global work queue
+//   k_cast_ray_chains    T1   two chained casts, the second started below the root next to the first one's hit
+//   k_render_sync*  R0 + S1..S4  the frame kernel: persistent waves take (tile, sample chunk) units from a work queue and run
+//                   each stage of a sample -- primary, shadow, GI, GI shadow -- for all 64 lanes together; a wave's tile is
+//                   8 x 8 pixels, or 4 x 4 pixels with four samples abreast (render_sync_body's NS)
 //   k_grid_cast     G1   Grid3D::castRay (grid_3d.hpp:36-132)
 //   k_resolve / k_resolve_shard / k_fill_u32 / k_pack_shard / k_unpack_shards   S4 sink + multi-GPU shard plumbing
 //
-// The three frame kernels produce bit-identical results (DESIGN.md section 4 has the measurements).
+// Rounds 1-3 carried two more schedulers of the same frame (k_render: persistent lanes running a mixed-stage state machine
+// with refill from a global queue; k_render_tile: lockstep primary / shadow, then GI jobs from a per-wave LDS pool filled by
+// ballot + prefix-sum compaction -- north_star's wording).  Both lost to the stage-synchronous kernel by 2x in round 1, the
+// refill scheme again in round 3's simulation at today's walk cost (tests/tools/refill_study.py: +5 % at its best threshold),
+// and were removed in round 4.
 // No MFMA anywhere: this is dependent 8-byte gathers, not a contraction.
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see build.py).
 #include <hip/hip_runtime.h>
@@ -187,19 +188,10 @@ k_grid_cast(const uint8_t* __restrict__ cells, int X, int Y, int Z, uint64_t n,
 }
 
 // ---------------------------------------------------------------------------
-// R0 + S1..S4: persistent-threads frame kernel
+// R0 + S1..S4: colour arithmetic and pixel selection shared by the frame kernels
 // ---------------------------------------------------------------------------
 
 namespace {
-
-enum Stage : uint32_t {
-    ST_NEED_WORK = 0,  // lane has no pixel
-    ST_PRIMARY = 1,    // raycaster.hpp:131
-    ST_SHADOW = 2,     // raycaster.hpp:153
-    ST_GI = 3,         // raycaster.hpp:194
-    ST_GI_SHADOW = 4,  // raycaster.hpp:198
-    ST_DONE = 5,       // queue exhausted
-};
 
 // utils.cpp:43-48 on a packed 0x00BBGGRR colour
 __device__ __forceinline__ uint32_t color_mult(uint32_t c, float f)
@@ -238,640 +230,6 @@ __device__ __forceinline__ bool pixel_selected(const vrc_frame_params& p, uint32
 
 }  // namespace
 
-extern "C" __global__ void __launch_bounds__(VRC_RENDER_BLOCK)
-k_render(const FrameArgs a)
-{
-    extern __shared__ stack_t lds_dyn[];               // [depth][VRC_RENDER_BLOCK] stack, then 1536 B textures
-    stack_t* stk = lds_dyn + threadIdx.x;
-    uint8_t* tex = reinterpret_cast<uint8_t*>(lds_dyn + a.depth * VRC_RENDER_BLOCK);
-    for (uint32_t i = threadIdx.x; i < 1536u / 4u; i += VRC_RENDER_BLOCK)
-        reinterpret_cast<uint32_t*>(tex)[i] = reinterpret_cast<const uint32_t*>(a.tex)[i];
-    __syncthreads();
-
-    const uint2* __restrict__ nodes = a.nodes;
-    const uint2 root = nodes[0];
-    const int depth = (int)a.depth;
-    const uint32_t W = a.width, H = a.height;
-    const float inv_size = 1.0f / (float)(1u << a.depth);                 // main.cpp:82
-    const float n_normalizer = inv_size * 0.0078125f * 2.0f;              // raycaster.hpp:171-172
-    const float lx = a.p.light_position[0], ly = a.p.light_position[1], lz = a.p.light_position[2];
-    const uint32_t shadow_samples = a.p.shadow_samples ? a.p.shadow_samples : (a.p.use_samples ? 4u : 1u);
-    const uint32_t gi_bounces = a.p.gi_bounces ? a.p.gi_bounces : 1u;
-    const uint32_t spp = a.p.spp ? a.p.spp : 1u;
-    const uint32_t tiles_per_row = (W + 7u) / 8u;
-
-    // wave-uniform work chunk [cur, end)
-    uint32_t cur = 0u, end = 0u;
-    bool exhausted = false;
-
-    // per-lane pixel program state
-    uint32_t stage = ST_NEED_WORK;
-    uint32_t pix = 0u, px_x = 0u, px_y = 0u, sample = 0u;
-    uint32_t acc_r = 0u, acc_g = 0u, acc_b = 0u;   // this pixel's colour summed over the samples of this call
-    uint32_t albedo = 0u;
-    float base_px = 0, base_py = 0, base_pz = 0;   // point the next GI ray starts from
-    float base_nx = 0, base_ny = 0, base_nz = 0;
-    float light_intensity = 0.0f;
-    float pending = 0.0f;                           // value applied if the current shadow-type ray is unoccluded
-    float dot_gi = 0.0f, dot_gi0 = 0.0f, acc0 = 0.0f, acc1 = 0.0f;
-    uint32_t shadow_left = 0u, gi_level = 0u, draw = 0u;
-    // current ray
-    Ray r;
-    float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, coef = 0.0f;
-    bool active = false;
-    // stats
-    uint32_t n_rays = 0u, n_steps = 0u, n_hits = 0u, n_pix = 0u;
-
-    for (;;) {
-        // ------------------------------------------------------------------
-        // traversal phase: step every active lane until enough lanes wait
-        // ------------------------------------------------------------------
-        for (;;) {
-            const uint64_t act = __ballot(active);
-            if (act == 0ull) break;
-            const uint64_t waiting = __ballot(!active && stage != ST_DONE);
-            if ((uint32_t)__popcll(waiting) >= a.refill_threshold) break;
-            if (active) active = ray_step<VRC_RENDER_BLOCK>(r, nodes, stk, depth, coef, 0.0f);
-        }
-
-        // ------------------------------------------------------------------
-        // transition phase: lanes whose ray ended consume the result
-        // ------------------------------------------------------------------
-        bool launch = false;        // a secondary ray (ox.., dx.., coef) is ready to start
-        bool gen_primary = false;   // generate the next sample's camera ray for (px_x, px_y)
-        bool sample_done = false;
-        uint32_t final_color = 0u;
-        if (!active && stage >= ST_PRIMARY && stage <= ST_GI_SHADOW) {
-            n_rays += 1u;
-            n_steps += r.complexity;
-            if (stage == ST_PRIMARY) {
-                Hit h;
-                ray_finish(r, depth, ox, oy, oz, dx, dy, dz, h);
-                if (a.prim && sample == 0u) {
-                    uint4* o = reinterpret_cast<uint4*>(a.prim + pix);
-                    o[0] = make_uint4(f2u(h.px), f2u(h.py), f2u(h.pz), f2u(h.nx));
-                    o[1] = make_uint4(f2u(h.ny), f2u(h.nz), f2u(h.u), f2u(h.v));
-                    o[2] = make_uint4(h.hit, h.node, f2u(h.distance), h.complexity);
-                }
-                if (!h.hit) {                                            // raycaster.hpp:135 miss -> Black
-                    sample_done = true; final_color = 0u;
-                } else {
-                    n_hits += 1u;
-                    // raycaster.hpp:209-240 albedo
-                    const uint8_t* img = (h.ny != 0.0f) ? tex : tex + 768;
-                    const float tu = clampf_(h.u, 0.0f, 1.0f), tv = clampf_(h.v, 0.0f, 1.0f);
-                    uint32_t idx = (uint32_t)(16.0f * tu) + (uint32_t)(16.0f * tv) * 16u;
-                    idx = min(idx, 255u);
-                    albedo = (uint32_t)img[idx * 3] | ((uint32_t)img[idx * 3 + 1] << 8) | ((uint32_t)img[idx * 3 + 2] << 16);
-                    base_px = h.px; base_py = h.py; base_pz = h.pz;
-                    base_nx = h.nx; base_ny = h.ny; base_nz = h.nz;
-                    // raycaster.hpp:139,150-153 shadow ray
-                    ox = h.px + h.nx * inv_size * 0.001f;
-                    oy = h.py + h.ny * inv_size * 0.001f;
-                    oz = h.pz + h.nz * inv_size * 0.001f;
-                    dx = lx - ox; dy = ly - oy; dz = lz - oz;
-                    normalize3(dx, dy, dz);
-                    pending = smax(0.0f, dot3(dx, dy, dz, h.nx, h.ny, h.nz));   // :156
-                    light_intensity = 0.0f;
-                    shadow_left = shadow_samples;
-                    coef = 0.0f;
-                    stage = ST_SHADOW;
-                    launch = true;
-                }
-            } else if (stage == ST_SHADOW) {
-                if (!r.kind) light_intensity = pending;                  // :155-157
-                shadow_left -= 1u;
-                if (shadow_left != 0u) {
-                    // the reference re-casts the identical ray (jitter commented out, :151)
-                    dx = lx - ox; dy = ly - oy; dz = lz - oz;
-                    normalize3(dx, dy, dz);
-                    launch = true;
-                } else if (a.p.use_gi) {
-                    gi_level = 0u; acc0 = 0.0f; acc1 = 0.0f;
-                    stage = ST_GI;      // ray generated below
-                } else {
-                    sample_done = true;
-                    final_color = color_mult(albedo, smin(1.0f, smax(0.0f, light_intensity + 0.0f)));  // :161-163
-                }
-            } else if (stage == ST_GI) {
-                Hit g;
-                ray_finish(r, depth, ox, oy, oz, dx, dy, dz, g);
-                if (g.hit) {                                             // raycaster.hpp:195-198
-                    base_px = g.px; base_py = g.py; base_pz = g.pz;
-                    base_nx = g.nx; base_ny = g.ny; base_nz = g.nz;
-                    ox = g.px + g.nx * n_normalizer;
-                    oy = g.py + g.ny * n_normalizer;
-                    oz = g.pz + g.nz * n_normalizer;
-                    dx = lx - ox; dy = ly - oy; dz = lz - oz;
-                    normalize3(dx, dy, dz);
-                    const float dotl = dot3(g.nx, g.ny, g.nz, dx, dy, dz);                     // :200
-                    pending = 1000000.0f * smin(0.5f, smax(0.0f, dotl) * dot_gi);              // :201
-                    coef = 0.5f;
-                    stage = ST_GI_SHADOW;
-                    launch = true;
-                } else {
-                    stage = ST_NEED_WORK + 100u;  // GI chain ends here
-                }
-            } else {  // ST_GI_SHADOW
-                if (gi_level == 0u) { if (!r.kind) acc0 += pending; }
-                else                { if (!r.kind) acc1 += pending; }
-                if (gi_level + 1u < gi_bounces) {
-                    dot_gi0 = dot_gi; gi_level += 1u;
-                    stage = ST_GI;      // extension: next bounce starts from the GI hit (base_*)
-                } else {
-                    stage = ST_NEED_WORK + 100u;
-                }
-            }
-            if (stage == ST_GI) {
-                // raycaster.hpp:174-194: GI ray from (base_p, base_n)
-                ox = base_px + base_nx * n_normalizer;
-                oy = base_py + base_ny * n_normalizer;
-                oz = base_pz + base_nz * n_normalizer;
-                const float c1 = get_rand(counter_rand(a.p.seed, a.p.frame_index + sample, pix, draw), -1000.0f, 1000.0f);
-                const float c2 = get_rand(counter_rand(a.p.seed, a.p.frame_index + sample, pix, draw + 1u), -1000.0f, 1000.0f);
-                draw += 2u;
-                float qx = 0.0f, qy = 0.0f, qz = 0.0f;
-                if (base_nx != 0.0f)      { qy = c1; qz = c2; }
-                else if (base_ny != 0.0f) { qx = c1; qz = c2; }
-                else if (base_nz != 0.0f) { qx = c1; qy = c2; }
-                dx = (base_nx + qx) * n_normalizer;
-                dy = (base_ny + qy) * n_normalizer;
-                dz = (base_nz + qz) * n_normalizer;
-                normalize3(dx, dy, dz);
-                dot_gi = dot3(dx, dy, dz, base_nx, base_ny, base_nz);    // :193
-                coef = 0.5f;
-                launch = true;
-            } else if (stage == ST_NEED_WORK + 100u) {
-                // raycaster.hpp:206 + nested extension: gi = max(0, acc0 [+ dot_gi0 * max(0, acc1)])
-                float gi;
-                if (gi_level == 0u) gi = smax(0.0f, acc0 / 1.0f);
-                else { acc0 += dot_gi0 * smax(0.0f, acc1 / 1.0f); gi = smax(0.0f, acc0 / 1.0f); }
-                sample_done = true;
-                final_color = color_mult(albedo, smin(1.0f, smax(0.0f, light_intensity + gi)));   // :163
-            }
-            if (sample_done) {
-                n_pix += 1u;
-                if (a.p.use_samples) { acc_r += final_color & 0xffu; acc_g += (final_color >> 8) & 0xffu; acc_b += (final_color >> 16) & 0xffu; }
-                else {
-                    // raycaster.hpp:77-85 temporal blend against the stored pixel
-                    uint32_t old = reinterpret_cast<uint32_t*>(a.image)[pix];
-                    const uint32_t alpha = old & 0xff000000u;
-                    old = color_mult(old & 0xffffffu, 0.4f);
-                    const uint32_t nw = color_mult(final_color, 1.0f - 0.4f);
-                    reinterpret_cast<uint32_t*>(a.image)[pix] = color_add_sat(old, nw) | alpha;
-                }
-                sample += 1u;
-                if (sample < spp) { gen_primary = true; }
-                else {
-                    if (a.p.use_samples) {
-                        uint4* ap = reinterpret_cast<uint4*>(a.accum) + pix;   // raycaster.hpp:87-90
-                        uint4 v = *ap;
-                        v.x += acc_r; v.y += acc_g; v.z += acc_b; v.w += spp;
-                        *ap = v;
-                    }
-                    stage = ST_NEED_WORK;
-                }
-            }
-        }
-
-        // ------------------------------------------------------------------
-        // refill: lanes without a pixel take consecutive work items
-        // ------------------------------------------------------------------
-        {
-            bool need = (stage == ST_NEED_WORK);
-            uint64_t mask = __ballot(need);
-            while (mask != 0ull && !exhausted) {
-                if (cur >= end) {
-                    uint32_t base = 0u;
-                    if (__lane_id() == 0u) base = atomicAdd(a.queue, a.chunk);
-                    base = __builtin_amdgcn_readfirstlane(base);
-                    if (base >= a.n_items) { exhausted = true; break; }
-                    cur = base;
-                    end = base + min(a.chunk, a.n_items - base);   // no wrap: base < n_items
-                }
-                const uint32_t avail = end - cur;
-                const uint32_t cnt = (uint32_t)__popcll(mask);
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                if (need && rank < avail) {
-                    const uint32_t item = cur + rank;
-                    const uint32_t t = item >> 6, l = item & 63u;
-                    const uint32_t tx = t % tiles_per_row, ty = t / tiles_per_row;
-                    const uint32_t x = tx * 8u + (l & 7u);
-                    uint32_t y = ty * 8u + (l >> 3);
-                    if (a.p.row_block && a.p.shard_count > 1u)
-                        y = ((y / a.p.row_block) * a.p.shard_count + a.p.shard_index) * a.p.row_block + (y % a.p.row_block);
-                    if (x < W && y < H && pixel_selected(a.p, W, H, x, y)) {
-                        px_x = x; px_y = y; pix = y * W + x;
-                        sample = 0u; acc_r = acc_g = acc_b = 0u;
-                        stage = ST_PRIMARY;
-                        gen_primary = true;
-                    }
-                }
-                cur += min(cnt, avail);
-                need = (stage == ST_NEED_WORK);
-                mask = __ballot(need);
-            }
-            if (exhausted && stage == ST_NEED_WORK) stage = ST_DONE;
-        }
-
-        // ------------------------------------------------------------------
-        // R0: camera ray for (px_x, px_y), sample `sample`
-        // (main.cpp:133,145-149; camera_controller.hpp:34-54)
-        // ------------------------------------------------------------------
-        if (gen_primary) {
-            const float aspect_ratio = (float)W / (float)H;
-            const float lens_x = (float)px_x / (float)H - aspect_ratio * 0.5f;
-            const float lens_y = (float)px_y / (float)H - 0.5f;
-            float sx = lens_x, sy = lens_y, sz = a.cam.fov;
-            normalize3(sx, sy, sz);
-            const float fx = sx * a.cam.focal_length, fy = sy * a.cam.focal_length, fz = sz * a.cam.focal_length;
-            const uint32_t fr = a.p.frame_index + sample;
-            const float r0 = get_rand(counter_rand(a.p.seed, fr, pix, 0u), -0.5f, 0.5f);
-            const float r1 = get_rand(counter_rand(a.p.seed, fr, pix, 1u), -0.5f, 0.5f);
-            draw = 2u;
-            const float rvx = a.cam.aperture * r0, rvy = a.cam.aperture * r1, rvz = a.cam.aperture * 0.0f;
-            float vx = fx - rvx, vy = fy - rvy, vz = fz - rvz;
-            normalize3(vx, vy, vz);
-            const float* m = a.cam.rot;
-            dx = (m[0] * vx + m[1] * vy) + m[2] * vz;
-            dy = (m[3] * vx + m[4] * vy) + m[5] * vz;
-            dz = (m[6] * vx + m[7] * vy) + m[8] * vz;
-            const float wx = (m[0] * rvx + m[1] * rvy) + m[2] * rvz;
-            const float wy = (m[3] * rvx + m[4] * rvy) + m[5] * rvz;
-            const float wz = (m[6] * rvx + m[7] * rvy) + m[8] * rvz;
-            ox = (a.cam.position[0] + wx) * inv_size + 1.0f;
-            oy = (a.cam.position[1] + wy) * inv_size + 1.0f;
-            oz = (a.cam.position[2] + wz) * inv_size + 1.0f;
-            coef = 0.0f;
-            stage = ST_PRIMARY;
-            launch = true;
-        }
-        if (launch) active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
-        if (__ballot(stage != ST_DONE) == 0ull) break;
-    }
-
-    // stats: wave reduction, one atomic per wave and counter
-    uint64_t s_rays = n_rays, s_steps = n_steps, s_hits = n_hits, s_pix = n_pix;
-    for (int off = 32; off > 0; off >>= 1) {
-        s_rays += __shfl_down(s_rays, off);
-        s_steps += __shfl_down(s_steps, off);
-        s_hits += __shfl_down(s_hits, off);
-        s_pix += __shfl_down(s_pix, off);
-    }
-    if (__lane_id() == 0u) {
-        uint64_t* slot = a.stats + 8u * (blockIdx.x % VRC_STAT_SLOTS);
-        atomicAdd(reinterpret_cast<unsigned long long*>(slot + 0), (unsigned long long)s_rays);
-        atomicAdd(reinterpret_cast<unsigned long long*>(slot + 1), (unsigned long long)s_steps);
-        atomicAdd(reinterpret_cast<unsigned long long*>(slot + 2), (unsigned long long)s_hits);
-        atomicAdd(reinterpret_cast<unsigned long long*>(slot + 3), (unsigned long long)s_pix);
-    }
-}
-
-// ---------------------------------------------------------------------------
-// R0 + S1..S4, tile-phased: coherent rays in lockstep, GI rays from an LDS pool
-// ---------------------------------------------------------------------------
-//
-// One wave owns one 8x8 pixel tile at a time (tile index from a global queue)
-// and runs it in two phases per pass of up to TILE_SPP samples:
-//
-//   phase A  every lane: camera ray -> walk -> shade -> shadow ray(s) -> walk.
-//            The 64 primaries of a tile (and their shadow rays) visit nearly the
-//            same nodes, so the wave stays in lockstep and executes one of the
-//            descend / advance / pop paths per iteration instead of all three
-//            (rocprofv3: 72 % lane utilisation vs 34 % with mixed stages).
-//            Pixel-samples that need GI are compacted into a per-wave job pool
-//            in LDS with ballot + prefix sum (mbcnt) -- "ray compaction between
-//            bounces" without a trip through HBM.
-//   phase B  lanes pull GI jobs from the pool (wave-uniform cursor, ballot +
-//            prefix sum again), each job = GI ray + its shadow ray (+ the
-//            second bounce of the extension); these rays are incoherent and
-//            short, so lanes are refilled as soon as `refill_threshold` of them
-//            wait.  Only GI stages exist here, which keeps the transition code
-//            (executed at partial utilisation) short.
-//
-// Per-lane float arithmetic and its order are exactly those of k_render and of
-// the oracle; only the schedule differs.
-
-#ifndef VRC_TILE_SPP
-#define VRC_TILE_SPP 4
-#endif
-#ifndef VRC_TILE_MIN_WAVES
-#define VRC_TILE_MIN_WAVES 4
-#endif
-namespace {
-constexpr uint32_t TILE_SPP = VRC_TILE_SPP;          // samples per pass (pool = 64 * TILE_SPP jobs)
-constexpr uint32_t TILE_POOL = 64u * TILE_SPP;
-constexpr uint32_t TILE_WAVE_LDS = TILE_POOL * 4u * 5u + TILE_POOL;   // px,py,pz,an,li (u32) + meta (u8)
-}  // namespace
-
-extern "C" __global__ void __launch_bounds__(VRC_RENDER_BLOCK, VRC_TILE_MIN_WAVES)
-k_render_tile(const FrameArgs a)
-{
-    extern __shared__ stack_t lds_dyn[];   // [depth][256] stack | 4 x per-wave pool | 1536 B textures
-    stack_t* stk = lds_dyn + threadIdx.x;
-    uint8_t* lds_tail = reinterpret_cast<uint8_t*>(lds_dyn + a.depth * VRC_RENDER_BLOCK);
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    float* pool_px = reinterpret_cast<float*>(lds_tail + wave * TILE_WAVE_LDS);
-    float* pool_py = pool_px + TILE_POOL;
-    float* pool_pz = pool_py + TILE_POOL;
-    uint32_t* pool_an = reinterpret_cast<uint32_t*>(pool_pz + TILE_POOL);   // albedo | normal mask<<24 | normal signs<<27
-    float* pool_li = reinterpret_cast<float*>(pool_an + TILE_POOL);
-    uint8_t* pool_meta = reinterpret_cast<uint8_t*>(pool_li + TILE_POOL);   // lane | si<<6
-    // A finished job leaves its final colour in its own pool_px slot (the position is dead once the GI
-    // ray has been generated); the owning lane remembers the slot of each of its samples.
-    uint32_t* pool_color = reinterpret_cast<uint32_t*>(pool_px);
-    uint8_t* tex = lds_tail + 4u * TILE_WAVE_LDS;
-    for (uint32_t i = threadIdx.x; i < 1536u / 4u; i += VRC_RENDER_BLOCK)
-        reinterpret_cast<uint32_t*>(tex)[i] = reinterpret_cast<const uint32_t*>(a.tex)[i];
-    __syncthreads();
-
-    const uint2* __restrict__ nodes = a.nodes;
-    const uint2 root = nodes[0];
-    const int depth = (int)a.depth;
-    const uint32_t W = a.width, H = a.height;
-    const float inv_size = 1.0f / (float)(1u << a.depth);                 // main.cpp:82
-    const float n_normalizer = inv_size * 0.0078125f * 2.0f;              // raycaster.hpp:171-172
-    const float lx = a.p.light_position[0], ly = a.p.light_position[1], lz = a.p.light_position[2];
-    const uint32_t shadow_samples = a.p.shadow_samples ? a.p.shadow_samples : (a.p.use_samples ? 4u : 1u);
-    const uint32_t gi_bounces = a.p.gi_bounces ? a.p.gi_bounces : 1u;
-    const uint32_t spp = a.p.spp ? a.p.spp : 1u;
-    const uint32_t tiles_per_row = (W + 7u) / 8u;
-    const uint32_t n_tiles = a.n_items >> 6;
-    const bool sharded = a.p.row_block && a.p.shard_count > 1u;
-
-    uint32_t n_rays = 0u, n_steps = 0u, n_hits = 0u, n_pix = 0u;
-
-    for (;;) {
-        uint32_t tile = 0u;
-        if (lane == 0u) tile = atomicAdd(a.queue, 1u);
-        tile = __builtin_amdgcn_readfirstlane(tile);
-        if (tile >= n_tiles) break;
-        const uint32_t tx = tile % tiles_per_row, ty = tile / tiles_per_row;
-        const uint32_t px_x = tx * 8u + (lane & 7u);
-        uint32_t px_y = ty * 8u + (lane >> 3);
-        if (sharded) px_y = ((px_y / a.p.row_block) * a.p.shard_count + a.p.shard_index) * a.p.row_block + (px_y % a.p.row_block);
-        const bool valid = px_x < W && px_y < H && pixel_selected(a.p, W, H, px_x, px_y);
-        const uint32_t pix = px_y * W + px_x;
-        uint32_t acc_r = 0u, acc_g = 0u, acc_b = 0u;
-
-        for (uint32_t s0 = 0u; s0 < spp; s0 += TILE_SPP) {
-            const uint32_t ns = min(TILE_SPP, spp - s0);
-            uint32_t njobs = 0u;   // wave-uniform
-            uint32_t my_slots = 0u;          // 8 bits per sample of this pass: its job slot in the pool ...
-            uint32_t my_jobs = 0u;           // ... valid where bit si is set
-            uint32_t direct[TILE_SPP];       // colour of samples finished in phase A (no-GI mode / misses)
-#pragma unroll
-            for (uint32_t k = 0; k < TILE_SPP; ++k) direct[k] = 0u;
-
-            // ---------------- phase A: primary + shadow, lockstep ----------------
-#pragma unroll
-            for (uint32_t si = 0u; si < TILE_SPP; ++si) {
-                if (si >= ns) break;
-                const uint32_t sample = s0 + si;
-                const uint32_t fr = a.p.frame_index + sample;
-                bool hit = false;
-                uint32_t albedo = 0u;
-                float light_intensity = 0.0f;
-                Hit h;
-                h.hit = 0u; h.px = h.py = h.pz = 0.0f; h.nx = h.ny = h.nz = 0.0f;
-                if (valid) {
-                    // R0: main.cpp:133,145-149; camera_controller.hpp:34-54
-                    const float aspect_ratio = (float)W / (float)H;
-                    const float lens_x = (float)px_x / (float)H - aspect_ratio * 0.5f;
-                    const float lens_y = (float)px_y / (float)H - 0.5f;
-                    float sx = lens_x, sy = lens_y, sz = a.cam.fov;
-                    normalize3(sx, sy, sz);
-                    const float fx = sx * a.cam.focal_length, fy = sy * a.cam.focal_length, fz = sz * a.cam.focal_length;
-                    const float r0 = get_rand(counter_rand(a.p.seed, fr, pix, 0u), -0.5f, 0.5f);
-                    const float r1 = get_rand(counter_rand(a.p.seed, fr, pix, 1u), -0.5f, 0.5f);
-                    const float rvx = a.cam.aperture * r0, rvy = a.cam.aperture * r1, rvz = a.cam.aperture * 0.0f;
-                    float vx = fx - rvx, vy = fy - rvy, vz = fz - rvz;
-                    normalize3(vx, vy, vz);
-                    const float* m = a.cam.rot;
-                    float dx = (m[0] * vx + m[1] * vy) + m[2] * vz;
-                    float dy = (m[3] * vx + m[4] * vy) + m[5] * vz;
-                    float dz = (m[6] * vx + m[7] * vy) + m[8] * vz;
-                    const float wx = (m[0] * rvx + m[1] * rvy) + m[2] * rvz;
-                    const float wy = (m[3] * rvx + m[4] * rvy) + m[5] * rvz;
-                    const float wz = (m[6] * rvx + m[7] * rvy) + m[8] * rvz;
-                    float ox = (a.cam.position[0] + wx) * inv_size + 1.0f;
-                    float oy = (a.cam.position[1] + wy) * inv_size + 1.0f;
-                    float oz = (a.cam.position[2] + wz) * inv_size + 1.0f;
-                    Ray r;
-                    bool active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
-                    ray_run<VRC_RENDER_BLOCK, 0>(r, active, nodes, stk, depth, 0.0f, 0.0f);
-                    n_rays += 1u; n_steps += r.complexity;
-                    ray_finish(r, depth, ox, oy, oz, dx, dy, dz, h);               // raycaster.hpp:131
-                    if (a.prim && sample == 0u) {
-                        uint4* o = reinterpret_cast<uint4*>(a.prim + pix);
-                        o[0] = make_uint4(f2u(h.px), f2u(h.py), f2u(h.pz), f2u(h.nx));
-                        o[1] = make_uint4(f2u(h.ny), f2u(h.nz), f2u(h.u), f2u(h.v));
-                        o[2] = make_uint4(h.hit, h.node, f2u(h.distance), h.complexity);
-                    }
-                    if (h.hit) {
-                        hit = true;
-                        n_hits += 1u;
-                        // raycaster.hpp:209-240 albedo
-                        const uint8_t* img = (h.ny != 0.0f) ? tex : tex + 768;
-                        const float tu = clampf_(h.u, 0.0f, 1.0f), tv = clampf_(h.v, 0.0f, 1.0f);
-                        uint32_t idx = (uint32_t)(16.0f * tu) + (uint32_t)(16.0f * tv) * 16u;
-                        idx = min(idx, 255u);
-                        albedo = (uint32_t)img[idx * 3] | ((uint32_t)img[idx * 3 + 1] << 8) | ((uint32_t)img[idx * 3 + 2] << 16);
-                        // raycaster.hpp:139,150-158 shadow ray(s): the reference re-casts the identical ray
-                        ox = h.px + h.nx * inv_size * 0.001f;
-                        oy = h.py + h.ny * inv_size * 0.001f;
-                        oz = h.pz + h.nz * inv_size * 0.001f;
-                        for (uint32_t i = shadow_samples; i--;) {
-                            dx = lx - ox; dy = ly - oy; dz = lz - oz;
-                            normalize3(dx, dy, dz);
-                            const float lit = smax(0.0f, dot3(dx, dy, dz, h.nx, h.ny, h.nz));   // :156
-                            active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
-                            ray_run<VRC_RENDER_BLOCK, 0>(r, active, nodes, stk, depth, 0.0f, 0.0f);
-                            n_rays += 1u; n_steps += r.complexity;
-                            if (!r.kind) light_intensity = lit;                              // :155-157
-                        }
-                    }
-                }
-                if (a.p.use_gi) {
-                    // compact the pixel-samples that continue with GI into the wave's job pool
-                    const bool job = valid && hit;
-                    const uint64_t mask = __ballot(job);
-                    const uint32_t slot = njobs + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                    if (job) {
-                        pool_px[slot] = h.px; pool_py[slot] = h.py; pool_pz[slot] = h.pz;
-                        // normal components are +-(0,1,2,4): 3 mask bits + 3 sign bits restore them exactly
-                        const uint32_t nm = (h.nx != 0.0f ? 1u : 0u) | (h.ny != 0.0f ? 2u : 0u) | (h.nz != 0.0f ? 4u : 0u);
-                        const uint32_t sg = (f2u(h.nx) >> 31) | ((f2u(h.ny) >> 31) << 1) | ((f2u(h.nz) >> 31) << 2);
-                        pool_an[slot] = albedo | (nm << 24) | (sg << 27);
-                        pool_li[slot] = light_intensity;
-                        pool_meta[slot] = (uint8_t)(lane | (si << 6));
-                        my_slots |= slot << (8u * si);
-                        my_jobs |= 1u << si;
-                    }                                                                // else: miss -> sf::Color::Black
-                    njobs += (uint32_t)__popcll(mask);
-                } else {
-                    direct[si] = hit ? color_mult(albedo, smin(1.0f, smax(0.0f, light_intensity + 0.0f))) : 0u;  // :161-163
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-
-            // ---------------- phase B: GI jobs from the pool ----------------
-            if (a.p.use_gi && njobs != 0u) {
-                uint32_t next = 0u;            // wave-uniform pool cursor
-                uint32_t stage = ST_NEED_WORK; // ST_GI / ST_GI_SHADOW / ST_NEED_WORK / ST_DONE
-                uint32_t jmeta = 0u, jpix = 0u, jan = 0u, jslot = 0u, draw = 0u, gi_level = 0u;
-                float jlight = 0.0f;
-                float base_px = 0, base_py = 0, base_pz = 0, base_nx = 0, base_ny = 0, base_nz = 0;
-                float pending = 0.0f, dot_gi = 0.0f, dot_gi0 = 0.0f, acc0 = 0.0f, acc1 = 0.0f;
-                float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0;
-                Ray r;
-                bool active = false;
-                for (;;) {
-                    for (;;) {
-                        const uint64_t act = __ballot(active);
-                        if (act == 0ull) break;
-                        const uint64_t waiting = __ballot(!active && stage != ST_DONE);
-                        if ((uint32_t)__popcll(waiting) >= a.refill_threshold) break;
-                        if (active) active = ray_step<VRC_RENDER_BLOCK>(r, nodes, stk, depth, 0.5f, 0.0f);
-                    }
-                    bool launch = false, gen_gi = false, job_done = false;
-                    if (!active && (stage == ST_GI || stage == ST_GI_SHADOW)) {
-                        n_rays += 1u; n_steps += r.complexity;
-                        if (stage == ST_GI) {
-                            Hit g;
-                            ray_finish(r, depth, ox, oy, oz, dx, dy, dz, g);
-                            if (g.hit) {                                             // raycaster.hpp:195-198
-                                base_px = g.px; base_py = g.py; base_pz = g.pz;
-                                base_nx = g.nx; base_ny = g.ny; base_nz = g.nz;
-                                ox = g.px + g.nx * n_normalizer;
-                                oy = g.py + g.ny * n_normalizer;
-                                oz = g.pz + g.nz * n_normalizer;
-                                dx = lx - ox; dy = ly - oy; dz = lz - oz;
-                                normalize3(dx, dy, dz);
-                                const float dotl = dot3(g.nx, g.ny, g.nz, dx, dy, dz);                 // :200
-                                pending = 1000000.0f * smin(0.5f, smax(0.0f, dotl) * dot_gi);          // :201
-                                stage = ST_GI_SHADOW;
-                                launch = true;
-                            } else {
-                                job_done = true;
-                            }
-                        } else {
-                            if (gi_level == 0u) { if (!r.kind) acc0 += pending; }
-                            else                { if (!r.kind) acc1 += pending; }
-                            if (gi_level + 1u < gi_bounces) { dot_gi0 = dot_gi; gi_level += 1u; gen_gi = true; }
-                            else job_done = true;
-                        }
-                        if (job_done) {
-                            // raycaster.hpp:206 + nested extension, then :163
-                            float gi;
-                            if (gi_level == 0u) gi = smax(0.0f, acc0 / 1.0f);
-                            else { acc0 += dot_gi0 * smax(0.0f, acc1 / 1.0f); gi = smax(0.0f, acc0 / 1.0f); }
-                            pool_color[jslot] = color_mult(jan & 0xffffffu, smin(1.0f, smax(0.0f, jlight + gi)));
-                            stage = ST_NEED_WORK;
-                        }
-                    }
-                    // refill from the pool: waiting lanes take consecutive jobs
-                    {
-                        const bool need = (stage == ST_NEED_WORK);
-                        const uint64_t mask = __ballot(need);
-                        if (mask != 0ull) {
-                            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                            const uint32_t j = next + rank;
-                            if (need) {
-                                if (j < njobs) {
-                                    jslot = j;
-                                    jmeta = pool_meta[j];
-                                    jan = pool_an[j];
-                                    jlight = pool_li[j];
-                                    base_px = pool_px[j]; base_py = pool_py[j]; base_pz = pool_pz[j];
-                                    const uint32_t nm = (jan >> 24) & 7u, sg = (jan >> 27) & 7u;
-                                    base_nx = u2f(((sg & 1u) << 31) | ((nm & 1u) ? 0x3f800000u : 0u));
-                                    base_ny = u2f((((sg >> 1) & 1u) << 31) | ((nm & 2u) ? 0x40000000u : 0u));
-                                    base_nz = u2f((((sg >> 2) & 1u) << 31) | ((nm & 4u) ? 0x40800000u : 0u));
-                                    const uint32_t jl = jmeta & 63u;
-                                    const uint32_t jx = tx * 8u + (jl & 7u);
-                                    uint32_t jy = ty * 8u + (jl >> 3);
-                                    if (sharded) jy = ((jy / a.p.row_block) * a.p.shard_count + a.p.shard_index) * a.p.row_block + (jy % a.p.row_block);
-                                    jpix = jy * W + jx;
-                                    draw = 2u; gi_level = 0u; acc0 = 0.0f; acc1 = 0.0f;
-                                    gen_gi = true;
-                                } else {
-                                    stage = ST_DONE;
-                                }
-                            }
-                            next = min(njobs, next + (uint32_t)__popcll(mask));
-                        }
-                    }
-                    if (gen_gi) {
-                        // raycaster.hpp:174-194: GI ray from (base_p, base_n)
-                        const uint32_t fr = a.p.frame_index + s0 + (jmeta >> 6);
-                        ox = base_px + base_nx * n_normalizer;
-                        oy = base_py + base_ny * n_normalizer;
-                        oz = base_pz + base_nz * n_normalizer;
-                        const float c1 = get_rand(counter_rand(a.p.seed, fr, jpix, draw), -1000.0f, 1000.0f);
-                        const float c2 = get_rand(counter_rand(a.p.seed, fr, jpix, draw + 1u), -1000.0f, 1000.0f);
-                        draw += 2u;
-                        float qx = 0.0f, qy = 0.0f, qz = 0.0f;
-                        if (base_nx != 0.0f)      { qy = c1; qz = c2; }
-                        else if (base_ny != 0.0f) { qx = c1; qz = c2; }
-                        else if (base_nz != 0.0f) { qx = c1; qy = c2; }
-                        dx = (base_nx + qx) * n_normalizer;
-                        dy = (base_ny + qy) * n_normalizer;
-                        dz = (base_nz + qz) * n_normalizer;
-                        normalize3(dx, dy, dz);
-                        dot_gi = dot3(dx, dy, dz, base_nx, base_ny, base_nz);        // :193
-                        stage = ST_GI;
-                        launch = true;
-                    }
-                    if (launch) active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
-                    if (__ballot(stage != ST_DONE) == 0ull) break;
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-
-            // ---------------- sink: raycaster.hpp:77-91, samples in order ----------------
-            if (valid) {
-                n_pix += ns;
-#pragma unroll
-                for (uint32_t si = 0u; si < TILE_SPP; ++si) {
-                    if (si >= ns) break;
-                    const uint32_t c = ((my_jobs >> si) & 1u) ? pool_color[(my_slots >> (8u * si)) & 0xffu] : direct[si];
-                    if (a.p.use_samples) { acc_r += c & 0xffu; acc_g += (c >> 8) & 0xffu; acc_b += (c >> 16) & 0xffu; }
-                    else {
-                        uint32_t old = reinterpret_cast<uint32_t*>(a.image)[pix];
-                        const uint32_t alpha = old & 0xff000000u;
-                        old = color_mult(old & 0xffffffu, 0.4f);
-                        const uint32_t nw = color_mult(c, 1.0f - 0.4f);
-                        reinterpret_cast<uint32_t*>(a.image)[pix] = color_add_sat(old, nw) | alpha;
-                    }
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        }
-        if (valid && a.p.use_samples) {
-            uint4* ap = reinterpret_cast<uint4*>(a.accum) + pix;                     // raycaster.hpp:87-90
-            uint4 v = *ap;
-            v.x += acc_r; v.y += acc_g; v.z += acc_b; v.w += spp;
-            *ap = v;
-        }
-    }
-
-    uint64_t s_rays = n_rays, s_steps = n_steps, s_hits = n_hits, s_pix = n_pix;
-    for (int off = 32; off > 0; off >>= 1) {
-        s_rays += __shfl_down(s_rays, off);
-        s_steps += __shfl_down(s_steps, off);
-        s_hits += __shfl_down(s_hits, off);
-        s_pix += __shfl_down(s_pix, off);
-    }
-    if (lane == 0u) {
-        uint64_t* slot = a.stats + 8u * (blockIdx.x % VRC_STAT_SLOTS);
-        atomicAdd(reinterpret_cast<unsigned long long*>(slot + 0), (unsigned long long)s_rays);
-        atomicAdd(reinterpret_cast<unsigned long long*>(slot + 1), (unsigned long long)s_steps);
-        atomicAdd(reinterpret_cast<unsigned long long*>(slot + 2), (unsigned long long)s_hits);
-        atomicAdd(reinterpret_cast<unsigned long long*>(slot + 3), (unsigned long long)s_pix);
-    }
-}
-
 // ---------------------------------------------------------------------------
 // R0 + S1..S4, stage-synchronous per tile ("sync" kernel)
 // ---------------------------------------------------------------------------
@@ -883,8 +241,8 @@ k_render_tile(const FrameArgs a)
 // registers and the per-wave LDS stack; no job pool, no state machine, so the
 // kernel needs few registers (high occupancy) and every transition (ray
 // generation, the three IEEE divides of ray_setup, finish, shading) runs at full
-// lane utilisation.  Measured against the two schedulers above on C3 it is the
-// fastest: what the refill machinery saves in idle lanes it loses in transition
+// lane utilisation.  Measured against the two refill schedulers of rounds 1-3 on C3
+// it was the fastest: what refill machinery saves in idle lanes it loses in transition
 // code executed at partial utilisation and in occupancy.
 
 // entries from one row of a stack to the next: the sync kernels keep two stacks with interleaved rows (render_sync_body)
@@ -1366,6 +724,8 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
 #endif
                 if (valid && (NS == 1u || sample < s_end)) {
                     // R0: main.cpp:133,145-149; camera_controller.hpp:34-54
+                    // (lens_x / lens_y / the focal point depend on the pixel only, camera_controller.hpp:36-39; hoisting them out of the
+                    // sample loop was measured in round 4: 1.254 vs 1.246 ms with frames in flight, 1.336 vs 1.348 alone -- noise)
                     const float aspect_ratio = (float)W / (float)H;
                     const float lens_x = (float)px_x / (float)H - aspect_ratio * 0.5f;
                     const float lens_y = (float)px_y / (float)H - 0.5f;
@@ -1399,7 +759,12 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
                         ray_start_at_camera(r, cam_scale < 22u ? my_cam_path[15] : 22u, ox, oy, oz);
                         copy_camera_path<VRC_SYNC_ROW>(stk, my_cam_path, depth, cam_scale);
                     } else {
-                        // the lens point is next to the camera position: it starts where their paths from the root part
+                        // The lens point is next to the camera position: it starts where their paths from the root part.  (A camera
+                        // ON a centre plane of the cube -- the reference's pose, x = z = 1.5 -- starts its lens rays at the root: the
+                        // margin test fails at every scale.  Starting them on the camera path of their side of the plane was built
+                        // in round 4 -- 32 M iterations fewer per C4 frame, proven against the oracle -- and measured 1 % SLOWER:
+                        // the iterations saved are lockstep descends, the side selection costs registers the 7-wave build
+                        // does not have.  DESIGN.md section 9.)
                         copy_camera_path<VRC_SYNC_ROW>(stk, cam_path, depth, cam_scale);
                         ray_start_below(r, start_scale_next_to(ox, oy, oz, (a.cam.position[0] + 0.0f) * inv_size + 1.0f,
                                                                (a.cam.position[1] + 0.0f) * inv_size + 1.0f,
@@ -1784,8 +1149,6 @@ hipError_t launch_grid_cast(const uint8_t* cells, int X, int Y, int Z, uint64_t 
     return hipGetLastError();
 }
 
-uint32_t tile_wave_lds_bytes() { return TILE_WAVE_LDS; }
-uint32_t tile_max_blocks_per_cu() { return VRC_TILE_MIN_WAVES; }
 uint32_t sync_max_blocks_per_cu() { return VRC_SYNC_MIN_WAVES; }
 uint32_t sync_s4_waves(bool pinhole) { return pinhole ? VRC_SYNC_S4_WAVES : VRC_SYNC_S4_WAVES_LENS; }
 uint32_t sync_waves_for(bool pinhole, bool one_bounce, bool use_gi, bool whole_spp_units, uint64_t pixel_samples, uint32_t requested)
@@ -1813,18 +1176,10 @@ bool camera_is_pinhole(const vrc_camera& cam)
     return pinhole;
 }
 
-hipError_t launch_render(const FrameArgs& a, uint32_t grid_blocks, int kernel, hipStream_t st, const char** launched)
+hipError_t launch_render(const FrameArgs& a, uint32_t grid_blocks, hipStream_t st, const char** launched)
 {
     const char* name = "";
-    if (kernel == VRC_KERNEL_MIXED) {
-        name = "k_render";
-        const size_t lds = (size_t)a.depth * VRC_RENDER_BLOCK * sizeof(stack_t) + 1536;
-        hipLaunchKernelGGL(k_render, dim3(grid_blocks), dim3(VRC_RENDER_BLOCK), lds, st, a);
-    } else if (kernel == VRC_KERNEL_TILE) {
-        name = "k_render_tile";
-        const size_t lds = (size_t)a.depth * VRC_RENDER_BLOCK * sizeof(stack_t) + 4 * TILE_WAVE_LDS + 1536;
-        hipLaunchKernelGGL(k_render_tile, dim3(grid_blocks), dim3(VRC_RENDER_BLOCK), lds, st, a);
-    } else {
+    {
         const size_t lds = 2 * (size_t)a.depth * VRC_RENDER_BLOCK * sizeof(stack_t) + 1536 + 128 + VRC_CAMERA_PATH_BYTES + 32;   // two stacks, tables, the waves' counters, camera paths, iterations not executed
         const bool pinhole = camera_is_pinhole(a.cam);
         const bool one = a.p.gi_bounces <= 1u, fused = a.fused_resolve != 0u;

@@ -204,11 +204,8 @@ class RayCaster:
         self.frame_index += spp
 
     # scheduling knobs of THIS renderer (results never depend on them; see include/vrc.h)
-    def setKernel(self, kernel):
-        check(capi.load().vrc_renderer_set_kernel(self._h, kernel))
-
-    def setTuning(self, blocks_per_cu=0, refill_threshold=0, chunk=0):
-        check(capi.load().vrc_renderer_set_tuning(self._h, blocks_per_cu, refill_threshold, chunk))
+    def setTuning(self, blocks_per_cu=0):
+        check(capi.load().vrc_renderer_set_tuning(self._h, blocks_per_cu))
 
     def setSampleChunk(self, samples_per_unit):
         check(capi.load().vrc_renderer_set_sample_chunk(self._h, samples_per_unit))

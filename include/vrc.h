@@ -228,7 +228,7 @@ int vrc_render_frame(vrc_renderer *r, const vrc_camera *cam, const vrc_frame_par
  * p->use_samples and accumulators that are zero on entry (after creation, vrc_reset_samples, vrc_resolve_shard(reset)
  * or a previous call of this function); same image, same shard rows, same counters as the two calls.  Rows of dst_dev
  * that correspond to no image row (padding of the last row block / slot) are left untouched.  Frame kernels or modes
- * that cannot fuse (checkerboard, vrc_set_kernel 0 / 1) run the two calls instead. */
+ * that cannot fuse (checkerboard) run the two calls instead. */
 int vrc_render_frame_resolved(vrc_renderer *r, const vrc_camera *cam, const vrc_frame_params *p, void *dst_dev, void *stream);
 /* Optional: also record the primary-ray HitPoint of sample 0 per pixel into
  * prim_dev (device memory, width*height vrc_hit) during the next frames; NULL disables. */
@@ -271,6 +271,8 @@ int vrc_renderer_set_image_target(vrc_renderer *r, void *image_dev);
  * concurrent runs different names (a pid or a token in it).  create = 0: opens it; a segment that is smaller than `count`
  * asks for or was made for another count is VRC_ERR_INVALID, never a fault on first touch. */
 int vrc_ipc_flags_open(const char *name, uint32_t count, int device, int create, vrc_ipc_flags **out);
+/* Host-side store to a flag (release order; e.g. an "everyone may leave" word the processes poll with vrc_ipc_flag_value). */
+int vrc_ipc_flag_set(vrc_ipc_flags *f, uint32_t index, uint32_t value);
 /* A stream-ordered wait (vrc_stream_wait_flag) HAS NO TIMEOUT: if the process that should write the flag died, the stream --
  * and every hipStreamSynchronize on it -- waits for ever.  So a host never synchronises such a stream blindly; it calls
  * vrc_ipc_stream_wait: polls `stream` until everything enqueued on it has completed (VRC_OK), or until one of the peers
@@ -344,19 +346,10 @@ void vrc_make_rotation(float angle_x, float angle_y, float rot[9]);
 /* Scheduling knobs.  vrc_set_* change the process-wide DEFAULTS that new renderers copy at
  * creation (thread-safe); vrc_renderer_set_* change one renderer (a renderer is not re-entrant,
  * so call them between its frames).  Results never depend on them.
- * Tuning knobs of the persistent frame kernel; 0 = default.
- * blocks_per_cu: resident 256-thread workgroups per CU (default 4);
- * refill_threshold: waiting lanes per wave that trigger a refill (default 32);
- * chunk: consecutive work items (pixels in 8x8-tile order) a wave reserves per
- * queue atomic (default 64 = one tile: keeps a wave's lanes on one tile). */
-int vrc_set_tuning(uint32_t blocks_per_cu, uint32_t refill_threshold, uint32_t chunk);
-/* Frame kernel.  2 = stage-synchronous per tile (default, fastest: a wave runs each
- * stage -- primary, shadow, GI, GI shadow -- of an 8x8 tile's sample together);
- * 0 = tile-phased with an LDS job pool for the GI rays (ballot + prefix-sum
- * compaction between bounces); 1 = persistent threads with mixed stages and a
- * global work queue.  Results are bit-identical; 0 and 1 are kept for A/B. */
-int vrc_set_kernel(uint32_t kernel);
-/* Stage-synchronous kernel, sample mode: samples per work unit (tile x sample chunk).  0 =
+ * blocks_per_cu: resident 256-thread workgroups of the frame kernel per CU (= waves per SIMD),
+ * 0 = the library's choice, at most 8 -- see vrc_renderer_last_kernel below for the builds. */
+int vrc_set_tuning(uint32_t blocks_per_cu);
+/* Sample mode: samples per work unit (tile x sample chunk).  0 =
  * automatic: the largest chunk that still gives every wave a few dozen units (down to 1 sample
  * per unit for small multi-GPU shards), and half that chunk for the tiles handed out last, so
  * that units get shorter towards the end of a launch; a pixel's samples split over several
@@ -370,8 +363,7 @@ int vrc_set_sample_chunk(uint32_t samples_per_unit);
  * vrc_renderer_last_kernel: the symbol of the frame kernel the renderer's last frame launched
  * (what a profile of the run lists), "" before the first frame. */
 const char *vrc_renderer_last_kernel(const vrc_renderer *r);
-int vrc_renderer_set_tuning(vrc_renderer *r, uint32_t blocks_per_cu, uint32_t refill_threshold, uint32_t chunk);
-int vrc_renderer_set_kernel(vrc_renderer *r, uint32_t kernel);
+int vrc_renderer_set_tuning(vrc_renderer *r, uint32_t blocks_per_cu);
 int vrc_renderer_set_sample_chunk(vrc_renderer *r, uint32_t samples_per_unit);
 /* Beyond the reference (off by default).  With aperture exactly +0 -- the reference's default
  * camera -- a pixel's primary ray and the shadow ray(s) of its hit are the same for every
@@ -380,7 +372,7 @@ int vrc_renderer_set_sample_chunk(vrc_renderer *r, uint32_t samples_per_unit);
  * pixel and frame with vrc_renderer_set_sample_chunk(r, spp)) and share the result between the
  * unit's samples; the GI rays stay per sample.  Image, accumulators and primary capture are bit
  * for bit the same; vrc_frame_stats.rays / sum_complexity then count the walks EXECUTED, i.e.
- * fewer than the reference's.  No effect with aperture != 0 or on the A/B kernels 0 and 1. */
+ * fewer than the reference's.  No effect with aperture != 0. */
 int vrc_renderer_set_invariant_ray_reuse(vrc_renderer *r, uint32_t on);
 /* Measurement switch (off by default): on = 1 makes the stage-synchronous kernel start EVERY ray at
  * the root, as lsvo.hpp:60-72 does, instead of below it next to the previous hit / the camera
@@ -396,8 +388,12 @@ int vrc_renderer_set_walk_from_root(vrc_renderer *r, uint32_t on);
  * lanes of a pixel share its primary hit: a stage's longest ray is the longest of 16 neighbouring
  * pixels', not of 64) -- for sample-mode frames (use_samples) with spp a multiple of 4, one GI
  * bounce and no checkerboard; other frames use map 1 whatever is set.  samples = 0 (default): the
- * library's choice.  Image, accumulators, captures and vrc_frame_stats are the same either way. */
+ * library's choice -- four abreast for a launch that has the chip to itself (3-6 % off a frame's
+ * latency), the pixel tiles for whole-spp work units (vrc_renderer_set_sample_chunk(r, spp): frames
+ * in flight, where they are 5 % faster).  Image, accumulators, captures and vrc_frame_stats are the
+ * same either way. */
 int vrc_renderer_set_lane_samples(vrc_renderer *r, uint32_t samples);
+int vrc_set_lane_samples(uint32_t samples);                 /* the process default new renderers copy */
 
 #ifdef __cplusplus
 }

@@ -111,10 +111,11 @@ void orc_model_camera_paths(const orc_lnode *raw, uint32_t depth, const float ca
 }
 
 /* One ray.  prev / prev_pos: state and hit position of the ray this one starts next to (NULL: start at the root); or cam: the
- * ray starts AT the camera position these paths were made for (org == that position).
+ * ray starts AT the camera position these paths were made for (org == that position); or cam + lens_of: the ray starts at a
+ * lens point NEXT TO the camera position lens_of (camera_controller.hpp:41,46: origin = position + rand_vec * rot).
  * *skipped = iterations not executed (already part of out->complexity). */
 static void model_cast(const orc_lnode *raw, uint32_t depth, const float org[3], const float dir[3], float coef, float bias,
-                       const orc_walk_state *prev, const float prev_pos[3], const orc_camera_paths *cam,
+                       const orc_walk_state *prev, const float prev_pos[3], const orc_camera_paths *cam, const float *lens_of,
                        orc_hit *out, orc_walk_state *st, uint32_t *skipped)
 {
     memset(out, 0, sizeof(*out));
@@ -147,6 +148,20 @@ static void model_cast(const orc_lnode *raw, uint32_t depth, const float org[3],
 
     float start_m[3] = { 0.0f, 0.0f, 0.0f };
     uint32_t start_mb = 0xffffffffu;
+    orc_walk_state lens_prev;
+    float lens_q[3];
+    if (cam && lens_of) {
+        /* the lens point is on one side of a centre plane the camera sits on by POSITION: it starts next to 1.5 - 1 ulp or
+         * next to 1.5 on that side's path, like a ray next to a hit there (a point on the plane, or within the margin of it,
+         * fails the margin test below and starts at the root) */
+        const uint32_t side = (px > 1.5f ? 1u : 0u) | (py > 1.5f ? 2u : 0u) | (pz > 1.5f ? 4u : 0u);
+        memcpy(lens_prev.rows, cam->rows[side], sizeof(lens_prev.rows));
+        lens_prev.scale = cam->scale[side];
+        lens_prev.valid = cam->scale[side] < 22u;
+        for (int i = 0; i < 3; i++)
+            lens_q[i] = ((cam->onplane >> i) & 1u) ? (((side >> i) & 1u) ? 1.5f : u2f(f2u(1.5f) - 1u)) : lens_of[i];
+        prev = &lens_prev; prev_pos = lens_q; cam = 0;
+    }
     if (cam) {
         const uint32_t v = mirror ^ 7u;
         const int s0 = (int)cam->scale[v];
@@ -294,7 +309,20 @@ static void model_cast(const orc_lnode *raw, uint32_t depth, const float org[3],
 void orc_model_cast(const orc_lnode *raw, uint32_t depth, const float org[3], const float dir[3], float coef, float bias,
                     const orc_walk_state *prev, const float prev_pos[3], orc_hit *out, orc_walk_state *st, uint32_t *skipped)
 {
-    model_cast(raw, depth, org, dir, coef, bias, prev, prev_pos, 0, out, st, skipped);
+    model_cast(raw, depth, org, dir, coef, bias, prev, prev_pos, 0, 0, out, st, skipped);
+}
+
+/* n camera rays of a camera with a lens: origins next to the camera position `cam` (camera_controller.hpp:41,46) */
+void orc_model_cast_lens_rays(const orc_lnode *raw, uint32_t depth, uint64_t n, const float cam[3], const float *org, const float *dir,
+                              orc_hit *out, orc_walk_state *st, uint32_t *skipped, uint32_t *scales, int threads)
+{
+    orc_camera_paths paths;
+    orc_model_camera_paths(raw, depth, cam, &paths);
+    if (scales) memcpy(scales, paths.scale, sizeof(paths.scale));
+    if (threads < 1) threads = 1;
+#pragma omp parallel for schedule(dynamic, 1024) num_threads(threads)
+    for (int64_t i = 0; i < (int64_t)n; i++)
+        model_cast(raw, depth, org + 3 * i, dir + 3 * i, 0.0f, 0.0f, 0, 0, &paths, cam, out + i, st + i, skipped + i);
 }
 
 /* n camera rays from one position (a pinhole camera's primary rays, main.cpp:149) */
@@ -307,7 +335,7 @@ void orc_model_cast_camera_rays(const orc_lnode *raw, uint32_t depth, uint64_t n
     if (threads < 1) threads = 1;
 #pragma omp parallel for schedule(dynamic, 1024) num_threads(threads)
     for (int64_t i = 0; i < (int64_t)n; i++)
-        model_cast(raw, depth, cam, dir + 3 * i, 0.0f, 0.0f, 0, 0, &paths, out + i, st + i, skipped + i);
+        model_cast(raw, depth, cam, dir + 3 * i, 0.0f, 0.0f, 0, 0, &paths, 0, out + i, st + i, skipped + i);
 }
 
 /* n independent chains: ray i starts next to hit i of the previous call (prev / prev_pos NULL: from the root) */

@@ -7,6 +7,7 @@
 // and compares all of them with the unsharded render.  The same code runs with one process per GPU of a node.
 //   peer_write_main <world> <depth> <width> <height> <spp> <frames> <top.rgb> <side.rgb>
 #include <hip/hip_runtime_api.h>
+#include <signal.h>
 #include <sys/wait.h>
 #include <unistd.h>
 
@@ -81,7 +82,8 @@ int main(int argc, char** argv)
         pipe.setShard(ROW_BLOCK, (uint32_t)rank, (uint32_t)world);
 
         // ---- set-up: rank 0 creates the flags and exports its F framebuffers; the others open both
-        const uint32_t n_flags = F * (uint32_t)world + F;       // written[slot][rank], then consumed[slot]
+        const uint32_t n_flags = F * (uint32_t)world + F + 1;   // written[slot][rank], then consumed[slot], then "everyone may leave"
+        const uint32_t all_done = n_flags - 1;
         auto written = [&](uint32_t slot, int k) { return slot * (uint32_t)world + (uint32_t)k; };
         auto consumed = [&](uint32_t slot) { return F * (uint32_t)world + slot; };
         vrc_ipc_flags* flags = nullptr;
@@ -128,6 +130,7 @@ int main(int argc, char** argv)
         if (rank == 0) for (pid_t k : kids) peer_pids.push_back((int32_t)k);
         else { peer_pids.push_back((int32_t)getppid()); for (pid_t k : kids) peer_pids.push_back((int32_t)k); }
         pipe.waitAllWatched(flags, peer_pids, 60000);
+        if (rank == 0) vrc_host::check(vrc_ipc_flag_set(flags, all_done, 1), "vrc_ipc_flag_set");   // every frame is complete: the writers may leave
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 
         if (rank == 0) {
@@ -150,6 +153,9 @@ int main(int argc, char** argv)
             for (void* p : keep) (void)hipFree(p);
             rc = equal ? 0 : 1;
         } else {
+            // a writer that has finished does not leave before the presenter has every frame: to the other ranks' watchdogs a
+            // process that is gone is a process that died (the flag is also released when the exchange is given up)
+            while (vrc_ipc_flag_value(flags, all_done) == 0 && kill(getppid(), 0) == 0) usleep(200);
             for (uint32_t s = 0; s < F; ++s) pipe.raycaster(s).setImageTarget(nullptr);
             for (void* t : targets) vrc_ipc_close_image(0, t);
         }

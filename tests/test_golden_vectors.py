@@ -75,9 +75,9 @@ def test_gpu_reproduces_frame_vector_and_hashes(built, textures):
         assert svo.n_nodes == want[str(depth)]["nodes"]
         assert fnv1a64_words(svo.downloadNodes().tobytes()) == want[str(depth)]["fnv1a64_of_u64_words"]
         if depth == 9:
-            for kernel in (2, 0, 1):
-                vrc.capi.check(vrc.capi.load().vrc_set_kernel(kernel))
+            for lane_samples in (1, 4):
                 rc = vrc.RayCaster(svo, (160, 90))
+                rc.setLaneSamples(lane_samples)
                 rc.setLightPosition(vrc.reference_light(9))
                 rc.use_gi = rc.use_samples = True
                 rc.shadow_samples = 1
@@ -85,4 +85,3 @@ def test_gpu_reproduces_frame_vector_and_hashes(built, textures):
                 st = rc.stats()
                 assert np.array_equal(rc.readAccum(), z["accum"])
                 assert (st.rays, st.sum_complexity) == (int(z["rays"]), int(z["steps"]))
-            vrc.capi.check(vrc.capi.load().vrc_set_kernel(2))

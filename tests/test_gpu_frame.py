@@ -10,14 +10,15 @@ import oracle_lib as O
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=[0, 1, 2], ids=["tile", "mixed", "sync"])
+@pytest.fixture(autouse=True, params=[1, 0], ids=["tiles8x8", "auto"])
 def frame_kernel(request, built):
-    """Every frame test runs on both frame kernels (vrc_set_kernel): 0 = tile-phased
-    1 = persistent threads with mixed stages, 2 = stage-synchronous per tile."""
+    """Every frame test runs with the 8 x 8 pixel map of the frame kernel forced and under the library's choice, which is four
+    samples abreast for the sample-mode frames here whose spp is a multiple of four (vrc_set_lane_samples;
+    tests/test_gpu_lane_map.py compares the two maps directly)."""
     import cpuvoxelraycaster_amd as vrc
-    vrc.capi.check(vrc.capi.load().vrc_set_kernel(request.param))
+    vrc.capi.check(vrc.capi.load().vrc_set_lane_samples(request.param))
     yield request.param
-    vrc.capi.check(vrc.capi.load().vrc_set_kernel(2))
+    vrc.capi.check(vrc.capi.load().vrc_set_lane_samples(0))
 
 
 @pytest.fixture(scope="module")
@@ -41,7 +42,7 @@ def run_pair(scene, textures, depth, W, H, pitch, spp=1, frames=1, use_gi=0, use
     nodes, svo = scene[depth]
     top, side = textures
     if tuning:
-        vrc.capi.check(vrc.capi.load().vrc_set_tuning(*tuning))
+        vrc.capi.check(vrc.capi.load().vrc_set_tuning(tuning[0]))
     rc = vrc.RayCaster(svo, (W, H))
     light = vrc.reference_light(depth)
     rc.setLightPosition(light)
@@ -70,7 +71,7 @@ def run_pair(scene, textures, depth, W, H, pitch, spp=1, frames=1, use_gi=0, use
             fi += 1
     st = rc.stats()
     if tuning:
-        vrc.capi.check(vrc.capi.load().vrc_set_tuning(0, 0, 0))
+        vrc.capi.check(vrc.capi.load().vrc_set_tuning(0))
     assert (st.rays, st.sum_complexity) == (rays, steps)
     if use_samples:
         assert np.array_equal(rc.readAccum(), oacc)
@@ -92,7 +93,7 @@ def test_primary_plus_shadow(scene, textures, pitch):
 
 
 def test_gi_sample_mode(scene, textures):
-    run_pair(scene, textures, 9, 320, 180, -0.5, spp=3, use_gi=1)
+    run_pair(scene, textures, 9, 320, 180, -0.5, spp=4, use_gi=1)
 
 
 def test_gi_reference_default_shadow_samples(scene, textures):
@@ -106,7 +107,7 @@ def test_gi_two_bounce_extension(scene, textures):
 
 
 def test_dof(scene, textures):
-    run_pair(scene, textures, 9, 320, 180, -0.5, spp=2, use_gi=1, aperture=0.5, focal_length=60.0)
+    run_pair(scene, textures, 9, 320, 180, -0.5, spp=4, use_gi=1, aperture=0.5, focal_length=60.0)
 
 
 def test_dof_two_bounce_extension(scene, textures):
@@ -119,7 +120,7 @@ def test_pinhole_shortcut_is_exact(scene, textures, aperture, focal_length):
     """aperture == +0 skips the two lens draws (rand_vec = 0 * getRand() is +-0): exact only while focal_point.x / .y
     cannot be -0, so negative / tiny focal lengths and a -0 aperture must take the general path.  Even widths put
     lens.x = +0 on the centre column (the case where the sign of a zero would show), primary hits are compared too."""
-    run_pair(scene, textures, 7, 160, 90, -0.5, spp=2, use_gi=1, aperture=aperture, focal_length=focal_length, capture=True)
+    run_pair(scene, textures, 7, 160, 90, -0.5, spp=4, use_gi=1, aperture=aperture, focal_length=focal_length, capture=True)
 
 
 def test_temporal_blend_checkerboard(scene, textures):
@@ -137,7 +138,7 @@ def test_checkerboard_sizes(scene, textures, size, use_samples):
 
 
 def test_odd_sizes(scene, textures):
-    run_pair(scene, textures, 7, 161, 93, -0.8, spp=2, use_gi=1)
+    run_pair(scene, textures, 7, 161, 93, -0.8, spp=4, use_gi=1)
     run_pair(scene, textures, 7, 7, 5, -0.8, spp=1, use_gi=0)
 
 

@@ -18,15 +18,13 @@ def scene(built, heights, textures):
     return nodes, vrc.LSVO(nodes, 7, textures=textures)
 
 
-def make(vrc, svo, W, H, chunk=None, kernel=None):
+def make(vrc, svo, W, H, chunk=None):
     rc = vrc.RayCaster(svo, (W, H))
     rc.setLightPosition(vrc.reference_light(7))
     rc.use_gi = rc.use_samples = True
     rc.shadow_samples = 1
     if chunk is not None:
         rc.setSampleChunk(chunk)
-    if kernel is not None:
-        rc.setKernel(kernel)
     return rc
 
 
@@ -78,8 +76,8 @@ def test_fused_frame_equals_oracle(scene, textures):
 
 
 def test_fused_falls_back_where_it_cannot_fuse(scene):
-    """tile-phased / mixed kernels: the same call runs render + resolve_shard; without use_samples it is an error;
-    mixing fused and plain frames on one renderer keeps the queue sets consistent."""
+    """without use_samples the call is an error; mixing fused and plain frames (and both lane maps) on one renderer keeps the
+    queue sets consistent."""
     import cpuvoxelraycaster_amd as vrc
     nodes, svo = scene
     W, H = 96, 56
@@ -87,15 +85,11 @@ def test_fused_falls_back_where_it_cannot_fuse(scene):
     ref = make(vrc, svo, W, H)
     ref.renderFrameResolved(cam, spp=3)
     want = ref.readImage()
-    for kernel in (0, 1):
-        rc = make(vrc, svo, W, H, kernel=kernel)
-        rc.renderFrameResolved(cam, spp=3)
-        assert np.array_equal(rc.readImage(), want) and not rc.readAccum().any()
     rc = make(vrc, svo, W, H)
     rc.use_samples = False
     with pytest.raises(vrc.VrcError):
         rc.renderFrameResolved(cam, spp=1)
-    # fused, plain + separate resolve, another kernel, fused again -- same renderer
+    # fused, plain + separate resolve, the other lane map, fused again -- same renderer
     rc = make(vrc, svo, W, H)
     for step in range(2):
         rc.frame_index = 0
@@ -106,12 +100,15 @@ def test_fused_falls_back_where_it_cannot_fuse(scene):
         rc.samples_to_image()
         assert np.array_equal(rc.readImage(), want)
         rc.resetSamples()
-        rc.setKernel(step)
+        rc.setLaneSamples(4 if step else 1)
+        rc.frame_index = 0
+        rc.renderFrame(cam, spp=4)
+        rc.resolveShard(reset=True)
         rc.frame_index = 0
         rc.renderFrame(cam, spp=3)
         rc.resolveShard(reset=True)
         assert np.array_equal(rc.readImage(), want)
-        rc.setKernel(2)
+        rc.setLaneSamples(0)
 
 
 def test_fused_full_size_c3(built, heights, textures):

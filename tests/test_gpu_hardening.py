@@ -85,12 +85,12 @@ def test_frame_limits_are_errors(built, heights, textures):
     with pytest.raises(vrc.VrcError):
         rc.setSampleChunk(70000)
     with pytest.raises(vrc.VrcError):
-        rc.setTuning(0, 0, (1 << 16) + 1)
+        rc.setTuning(9)
     with pytest.raises(vrc.VrcError):
-        rc.setKernel(3)
+        rc.setLaneSamples(2)
     rc.renderFrame(cam, spp=2)                          # still usable
     assert rc.stats().pixels == 64 * 40 * 2
-    assert L.vrc_set_tuning(9, 0, 0) == -1
+    assert L.vrc_set_tuning(9) == -1 and L.vrc_set_lane_samples(3) == -1
 
 
 def test_failed_call_does_not_poison_the_next_frames(built, heights, textures):
@@ -140,14 +140,14 @@ def test_scheduling_knobs_belong_to_the_renderer(built, heights, textures):
         return rc
 
     a, b, c = make(), make(), make()
-    a.setKernel(0)
-    b.setKernel(1)
+    a.setLaneSamples(1)
+    b.setTuning(3)
     c.setSampleChunk(1)
-    vrc.capi.check(L.vrc_set_kernel(1))                  # must not affect a, b, c
+    vrc.capi.check(L.vrc_set_lane_samples(4))            # must not affect a, b, c
     try:
         d = make()                                       # ... but seeds d
     finally:
-        vrc.capi.check(L.vrc_set_kernel(2))
+        vrc.capi.check(L.vrc_set_lane_samples(0))
     for f in range(2):
         for rc in (a, b, c, d):
             rc.renderFrame(cam, spp=3)

@@ -285,3 +285,74 @@ def test_constructed_margin_adversaries():
     # measured (6.65 M rays): [188963, 42174, 352, 0, 0, 0, 0, 0, 0] differ at margins 0..8 -- the walk first holds at 3 ulps, below
     # the 4.5 of the hand-derived bound; the shipped 8 keeps 5 ulps of slack over what these adversaries need
     assert first_ok <= 4, (first_ok, bad.tolist())
+
+
+def model_cast_lens(L, nodes, depth, cam_pos, org, dir_, threads=8):
+    """camera rays of a camera with a lens: origins next to cam_pos, started on the camera cell's path of their side"""
+    L.orc_model_cast_lens_rays.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64] + [C.c_void_p] * 7 + [C.c_int]
+    n = len(org)
+    org, dir_ = np.ascontiguousarray(org, np.float32), np.ascontiguousarray(dir_, np.float32)
+    cam_pos = np.ascontiguousarray(cam_pos, np.float32)
+    out, st, skipped, scales = np.zeros(n, O.HIT_DTYPE), np.zeros(n, STATE_DTYPE), np.zeros(n, np.uint32), np.zeros(8, np.uint32)
+    L.orc_model_cast_lens_rays(O._ptr(nodes), depth, n, O._ptr(cam_pos), O._ptr(org), O._ptr(dir_), O._ptr(out), O._ptr(st), O._ptr(skipped),
+                               O._ptr(scales), threads)
+    return out, st, skipped, scales
+
+
+@pytest.mark.parametrize("depth", [7, 9])
+def test_lens_rays_start_on_their_side_of_the_centre_planes(depth):
+    """A formulation that is proven here and NOT shipped (round 4, DESIGN.md section 9: measured 1 % slower on C4).  With a lens
+    (camera_controller.hpp:41,46) the ray starts at position + rand_vec * rot, next to the camera.  The reference's pose sits
+    exactly on the cube's centre planes x = z = 1.5, where the kernel starts every lens ray at the root; a lens point is on one
+    side of such a plane by POSITION, so it could start on that side's camera path -- unless it is on the plane or within the
+    margin of it (getRand's level 50 is exactly 0).  The model does that (orc_model_cast_lens_rays) and equals the oracle.
+    Origins: the aperture's real offsets, and constructed ones k = 0..16 ulps either side of the planes, x directions in every
+    octant and with +-EPS / +-0 components."""
+    import cpuvoxelraycaster_amd as vrc
+    L = model_lib()
+    nodes = vrc.build_terrain_lsvo(O.load_terrain_heights(), depth)
+    rng = np.random.default_rng(90 + depth)
+    f = np.float32
+    S = float(1 << depth)
+    ref_cam = vrc.reference_camera(depth, pitch=-0.5, make_rotation=lambda x, y: O.make_rotation(x, y))
+    poses = [np.asarray(ref_cam.position, f), np.asarray([S / 2, ref_cam.position[1] + 3.25, S / 2 + 7.3], f),
+             np.asarray([S / 2 + 11.7, S / 2 - 0.45 * S, S / 2 - 5.1], f)]
+    for k, pos in enumerate(poses):
+        cam_pos = (pos * (f(1.0) / f(S)) + f(1.0)).astype(f)
+        n = 120000
+        # rand_vec = aperture * (getRand(), getRand(), 0) with 100 levels in [-0.5, 0.5), rotated; aperture 0.5 .. 4 world units
+        ap = rng.choice([0.5, 1.0, 4.0], n)
+        lv = (rng.integers(0, 100, (n, 3)) / 100.0 - 0.5) * ap[:, None]
+        lv[:, 2] = 0.0
+        rot = np.asarray(O.make_rotation(float(rng.uniform(-3, 3)), -0.5), np.float64).reshape(3, 3)
+        w = (lv @ rot.T).astype(f)
+        org = ((pos[None, :] + w).astype(f) * (f(1.0) / f(S)) + f(1.0)).astype(f)
+        # ... a quarter of them constructed: +-k ulps off the camera's coordinate on one or more axes
+        m = n // 4
+        cb = cam_pos.view(np.uint32).astype(np.int64)
+        kk = rng.integers(0, 17, (m, 3)) * rng.choice([-1, 1], (m, 3)) * (rng.random((m, 3)) < 0.6)
+        org[:m] = (cb[None, :] + kk).astype(np.uint32).view(f)
+        d = normalize(rng.normal(size=(n, 3)))
+        d[::13, 0] = 0.0
+        d[::17, 2] = -0.0
+        d[::19, 1] = f(2.0 ** -23) * f(1.3)
+        ref = O.cast_rays(nodes, depth, org, d, 0.0, 0.0, threads=8)
+        mod, st, sk, scales = model_cast_lens(L, nodes, depth, cam_pos, org, d)
+        assert same(ref, mod), (k, pos)
+        on_plane = cam_pos == 1.5
+        far = (np.abs(org.view(np.uint32).astype(np.int64) - cb[None, :]) > 8)[:, on_plane].all(axis=1) if on_plane.any() else np.ones(n, bool)
+        assert scales.max() < 22
+        if on_plane.any():
+            assert (sk[far] > 0).mean() > 0.9, (k, (sk[far] > 0).mean())       # off the planes: they start below the root
+            near = (np.abs(org.view(np.uint32).astype(np.int64) - cb[None, :]) < 8)[:, on_plane].any(axis=1)
+            assert near.sum() > 1000 and (sk[near] == 0).all()                 # on / next to a plane: at the root
+        else:
+            assert (sk > 0).mean() > 0.9
+        # ... and the shadow rays of their hits start next to them on the path the lens ray's walk left
+        hit = ref["hit"] != 0
+        P, stP = ref[hit], np.ascontiguousarray(st[hit])
+        so = (P["position"] + (P["normal"] * (f(1.0) / f(S))) * f(0.001)).astype(f)
+        sd = normalize(np.asarray(vrc.reference_light(depth), f)[None, :] - so)
+        ref_s = O.cast_rays(nodes, depth, so, sd, 0.0, 0.0, threads=8)
+        mod_s, _, _ = model_cast(L, nodes, depth, so, sd, 0.0, stP, P["position"])
+        assert same(ref_s, mod_s), (k, pos)

@@ -48,7 +48,7 @@ def main():
             if got.tobytes() != ref.tobytes():
                 print("RAY MISMATCH", it, depth, len(org)); bad += 1
         else:
-            # random frame configuration on the terrain, random kernel
+            # random frame configuration on the terrain, random lane map
             if rng.integers(0, 2):
                 depth = int(rng.choice([7, 8, 9]))
                 svo = vrc.LSVO.fromFastNoiseTerrain(depth, textures=(top, side))
@@ -68,10 +68,10 @@ def main():
                 svo = vrc.LSVO.fromVolume(vol, depth, textures=(top, side))
             nodes = svo.downloadNodes()
             W, H = int(rng.integers(1, 200)), int(rng.integers(1, 120))
-            kernel = int(rng.integers(0, 3))
-            vrc.capi.check(L.vrc_set_kernel(kernel))
-            vrc.capi.check(L.vrc_set_sample_chunk(int(rng.integers(0, 8))))     # 0 = automatic ... whole-spp units
+            vrc.capi.check(L.vrc_set_sample_chunk(int(rng.integers(0, 9))))     # 0 = automatic ... whole-spp units
             rc = vrc.RayCaster(svo, (W, H))
+            lane_samples = int(rng.choice([0, 1, 4]))                          # the lane <-> (pixel, sample) map (4 applies to spp % 4 == 0)
+            rc.setLaneSamples(lane_samples)
             # a quarter of the cases with the invariant-ray reuse (pinhole camera + stage-synchronous kernel: fewer walks
             # executed, same frame; anything else: no effect at all)
             reuse = bool(rng.integers(0, 4) == 0)
@@ -103,7 +103,7 @@ def main():
                 light = (np.round(rng.uniform(1.0, 2.0, 3) * S) / S).astype(np.float32)
             if lk <= 2:
                 rc.setLightPosition(light)
-            spp = int(rng.integers(1, 7))
+            spp = int(rng.choice([1, 2, 3, 4, 4, 4, 5, 6, 8, 8, 12]))
             nfr = int(rng.integers(1, 3))
             checker = bool(rng.integers(0, 2))
             # a third of the frames are one rank's shard of a multi-GPU frame
@@ -135,7 +135,7 @@ def main():
                     mine = oacc[..., 3] > 0                                 # this shard's pixels
                     ok = ok and np.array_equal(rc.readImage()[mine], O.samples_to_image(oacc)[mine]) and not rc.readAccum().any()
             st = rc.stats()
-            if reuse and kernel == 2 and cam.aperture == 0.0:
+            if reuse and cam.aperture == 0.0:
                 ok = ok and st.rays <= rr and st.sum_complexity <= ss
             else:
                 ok = ok and (st.rays, st.sum_complexity) == (rr, ss)
@@ -144,9 +144,9 @@ def main():
             frames += 1
             rays_total += rr
             if not ok:
-                print("FRAME MISMATCH", it, dict(depth=depth, W=W, H=H, kernel=kernel, spp=spp, gi=rc.use_gi, samples=use_samples,
+                print("FRAME MISMATCH", it, dict(depth=depth, W=W, H=H, lane_samples=lane_samples, kernel=rc.lastKernel(), spp=spp, gi=rc.use_gi, samples=use_samples,
                                                  checker=checker, fused=fused, reuse=reuse, blocks=blocks, shard=(row_block, shard_index, shard_count))); bad += 1
-            vrc.capi.check(L.vrc_set_kernel(2)); vrc.capi.check(L.vrc_set_sample_chunk(0))
+            vrc.capi.check(L.vrc_set_sample_chunk(0))
     print(f"fuzz: {it} cases ({frames} frames), {rays_total} rays compared, {bad} mismatches, {time.time() - t0:.0f} s")
     sys.exit(1 if bad else 0)
 

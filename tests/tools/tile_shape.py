@@ -85,7 +85,7 @@ def trace_pose(L, O, vrc, nodes, tex, depth, W, Hh, pitch, aperture, band, threa
         if aperture == 0.0:     # every camera ray starts at the camera, on the path of its direction signs
             skip[:, :, 0] = np.where(trace[:, :, 0] > 0, 22 - cam_scales[signs[:, :, 0]], 0)
         else:                   # the lens point is next to the camera position: it starts where their paths from the root part
-            cs = int(cam_scales.min())
+            cs = int(cam_scales.min())   # (a camera on a centre plane of the cube: 22, its lens rays start at the root)
             s0 = start_scale_next_to(org[:, :, 0], np.broadcast_to(cam_pos, org[:, :, 0].shape), np.full(trace.shape[:2], cs))
             skip[:, :, 0] = np.where((s0 < 22) & (trace[:, :, 0] > 0), 22 - s0, 0)
         for ray, prev in ((1, 0), (2, 0), (3, 2)):

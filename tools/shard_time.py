@@ -23,7 +23,7 @@ print("N  bpc  median_ms   (ideal = t(N=1)/N)")
 base = None
 for N in (1, 2, 4, 8):
     for bpc in [int(v) for v in os.environ.get('BPCS', '3,5').split(',')]:
-        rc.setTuning(bpc, 24, 64)
+        rc.setTuning(bpc)
         ts = []
         for it in range(8):
             rc.resetSamples(stream)
