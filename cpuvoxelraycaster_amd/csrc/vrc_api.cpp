@@ -890,10 +890,19 @@ extern "C" int vrc_ipc_stream_wait(vrc_ipc_flags* f, void* stream, const int32_t
         }
         std::this_thread::sleep_for(std::chrono::microseconds(spins < 2000u ? 50 : 500));
     }
-    // give up for everyone: mark the segment, then release every wait on its flags (>= comparisons: the largest value passes all)
+    // give up for everyone: mark the segment, then release every wait on its flags (>= comparisons: the largest value passes all).
+    // The release has to be HELD while the stream drains: the stream-ordered flag writes still queued behind the waits (this
+    // process's and the peers') put ordinary frame numbers back into the flags, and a wait that comes after such a write would
+    // block again -- so the flags are re-asserted until this stream is empty (every process's own watchdog does the same for its
+    // stream; bounded, in case the device itself is gone).
     __atomic_store_n(f->host + f->count + FLAGS_HDR_GIVEN_UP, 1u, __ATOMIC_RELEASE);
-    for (uint32_t i = 0; i < f->count; ++i) __atomic_store_n(f->host + i, 0xffffffffu, __ATOMIC_RELEASE);
-    (void)hipStreamSynchronize((hipStream_t)stream);              // drains now: nothing waits any more
+    const auto t1 = std::chrono::steady_clock::now();
+    for (;;) {
+        for (uint32_t i = 0; i < f->count; ++i) __atomic_store_n(f->host + i, 0xffffffffu, __ATOMIC_RELEASE);
+        if (hipStreamQuery((hipStream_t)stream) != hipErrorNotReady) break;
+        if (std::chrono::duration_cast<std::chrono::seconds>(std::chrono::steady_clock::now() - t1).count() >= 20) break;
+        std::this_thread::sleep_for(std::chrono::microseconds(100));
+    }
     return fail(VRC_ERR_PEER, "vrc_ipc_stream_wait: %s (pid %d); every wait on %s was released, frames after this are not valid", why, (int)who, f->name);
 }
 

@@ -951,16 +951,23 @@ VRC_SYNC_KERNEL_NS(k_render_sync_pinhole_s4, true, true, false, VRC_SYNC_S4_WAVE
 VRC_SYNC_KERNEL_NS(k_render_sync_pinhole_resolved_s4, true, true, true, VRC_SYNC_S4_WAVES, 4u)
 #undef VRC_SYNC_KERNEL
 #undef VRC_SYNC_KERNEL_NS
-// the pinhole one-bounce kernels with every ray started at the root, as lsvo.hpp:60-72 does (vrc_renderer_set_walk_from_root: a
-// measurement switch -- bench.py's extra.every_ray_from_the_root says what the start below the root is worth)
-extern "C" __global__ void __launch_bounds__(VRC_RENDER_BLOCK, VRC_SYNC_MIN_WAVES) k_render_sync_pinhole_from_root(const FrameArgs a)
-{
-    render_sync_body<true, true, false, true>(a);
-}
-extern "C" __global__ void __launch_bounds__(VRC_RENDER_BLOCK, VRC_SYNC_MIN_WAVES) k_render_sync_pinhole_resolved_from_root(const FrameArgs a)
-{
-    render_sync_body<true, true, true, true>(a);
-}
+// every kernel of the 8 x 8 map once more with every ray started at the root, as lsvo.hpp:60-72 does
+// (vrc_renderer_set_walk_from_root: a measurement and A/B switch -- bench.py's extra.every_ray_from_the_root says what the start
+// below the root is worth; tests/test_gpu_start_below.py renders pinhole, lens and 2-bounce frames both ways and wants them equal)
+#define VRC_SYNC_KERNEL_ROOT(name, PINHOLE, ONE_BOUNCE, FUSED)                                                  \
+    extern "C" __global__ void __launch_bounds__(VRC_RENDER_BLOCK, VRC_SYNC_MIN_WAVES) name(const FrameArgs a)  \
+    {                                                                                                           \
+        render_sync_body<PINHOLE, ONE_BOUNCE, FUSED, true>(a);                                                  \
+    }
+VRC_SYNC_KERNEL_ROOT(k_render_sync_pinhole_from_root, true, true, false)
+VRC_SYNC_KERNEL_ROOT(k_render_sync_pinhole_resolved_from_root, true, true, true)
+VRC_SYNC_KERNEL_ROOT(k_render_sync_pinhole2_from_root, true, false, false)
+VRC_SYNC_KERNEL_ROOT(k_render_sync_pinhole2_resolved_from_root, true, false, true)
+VRC_SYNC_KERNEL_ROOT(k_render_sync_from_root, false, true, false)
+VRC_SYNC_KERNEL_ROOT(k_render_sync_resolved_from_root, false, true, true)
+VRC_SYNC_KERNEL_ROOT(k_render_sync2_from_root, false, false, false)
+VRC_SYNC_KERNEL_ROOT(k_render_sync2_resolved_from_root, false, false, true)
+#undef VRC_SYNC_KERNEL_ROOT
 
 // ---------------------------------------------------------------------------
 // S4 sink + plumbing
@@ -1190,8 +1197,11 @@ hipError_t launch_render(const FrameArgs& a, uint32_t grid_blocks, hipStream_t s
         const Build b =
             s4 ? (pinhole ? (fused ? VRC_BUILD(k_render_sync_pinhole_resolved_s4) : VRC_BUILD(k_render_sync_pinhole_s4))
                           : (fused ? VRC_BUILD(k_render_sync_resolved_s4) : VRC_BUILD(k_render_sync_s4))) :
+            a.walk_from_root ? (pinhole ? (one ? (fused ? VRC_BUILD(k_render_sync_pinhole_resolved_from_root) : VRC_BUILD(k_render_sync_pinhole_from_root))
+                                               : (fused ? VRC_BUILD(k_render_sync_pinhole2_resolved_from_root) : VRC_BUILD(k_render_sync_pinhole2_from_root)))
+                                        : (one ? (fused ? VRC_BUILD(k_render_sync_resolved_from_root) : VRC_BUILD(k_render_sync_from_root))
+                                               : (fused ? VRC_BUILD(k_render_sync2_resolved_from_root) : VRC_BUILD(k_render_sync2_from_root)))) :
             (waves == 7u && !pinhole && one) ? (fused ? VRC_BUILD(k_render_sync_resolved_w7) : VRC_BUILD(k_render_sync_w7)) :
-            (a.walk_from_root && pinhole && one) ? (fused ? VRC_BUILD(k_render_sync_pinhole_resolved_from_root) : VRC_BUILD(k_render_sync_pinhole_from_root)) :
             pinhole ? (one ? (fused ? VRC_BUILD(k_render_sync_pinhole_resolved) : VRC_BUILD(k_render_sync_pinhole))
                            : (fused ? VRC_BUILD(k_render_sync_pinhole2_resolved) : VRC_BUILD(k_render_sync_pinhole2)))
                     : (one ? (fused ? VRC_BUILD(k_render_sync_resolved) : VRC_BUILD(k_render_sync))

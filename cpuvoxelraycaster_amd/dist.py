@@ -159,8 +159,15 @@ class PeerFrames:
         import ctypes as C
         from . import capi
         pids = (C.c_int32 * len(self.pids))(*self.pids)
+        L, failed = capi.load(), None
         for s in streams:
-            capi.check(capi.load().vrc_ipc_stream_wait(self._flags, capi.ptr(s), pids, len(self.pids), int(timeout_s * 1000)))
+            # after a failure the remaining streams are still drained (each call holds the release while its stream empties):
+            # a process must not leave with a wait pending on the device
+            rc = L.vrc_ipc_stream_wait(self._flags, capi.ptr(s), pids, len(self.pids), int(timeout_s * 1000))
+            if rc != 0 and failed is None:
+                failed = capi.VrcError(f"vrc error {rc}: {L.vrc_last_error().decode()}")
+        if failed is not None:
+            raise failed
 
     def close(self):
         """after every rank has synchronised its streams (the caller's barrier)"""

@@ -350,8 +350,15 @@ public:
     // every wait on the flags is released in every process and this throws (VRC_ERR_PEER).
     void waitAllWatched(vrc_ipc_flags* flags, const std::vector<int32_t>& peer_pids, uint32_t timeout_ms = 120000)
     {
-        for (void* st : streams_)
-            check(vrc_ipc_stream_wait(flags, st, peer_pids.data(), (uint32_t)peer_pids.size(), timeout_ms), "vrc_ipc_stream_wait");
+        int first = 0;
+        std::string why;
+        for (void* st : streams_) {
+            // after a failure the remaining streams are still drained (each call holds the release while its stream empties): a
+            // process must not leave with a wait pending on the device
+            const int rc = vrc_ipc_stream_wait(flags, st, peer_pids.data(), (uint32_t)peer_pids.size(), timeout_ms);
+            if (rc != 0 && first == 0) { first = rc; why = vrc_last_error(); }
+        }
+        if (first != 0) throw std::runtime_error("vrc_ipc_stream_wait: " + why);
     }
     std::vector<uint8_t> image(uint32_t slot) { return slots_[slot]->render_image(streams_[slot]); }   // waits for that slot
     void* image_device_ptr(uint32_t slot) const { return vrc_image_device_ptr(slots_[slot]->handle()); }

@@ -374,12 +374,13 @@ int vrc_renderer_set_sample_chunk(vrc_renderer *r, uint32_t samples_per_unit);
  * for bit the same; vrc_frame_stats.rays / sum_complexity then count the walks EXECUTED, i.e.
  * fewer than the reference's.  No effect with aperture != 0. */
 int vrc_renderer_set_invariant_ray_reuse(vrc_renderer *r, uint32_t on);
-/* Measurement switch (off by default): on = 1 makes the stage-synchronous kernel start EVERY ray at
- * the root, as lsvo.hpp:60-72 does, instead of below it next to the previous hit / the camera
- *  -- for frames of a pinhole camera (aperture +0) with one GI bounce, the
- * reference's configuration, which have a build for it; other frames ignore it.  Same image, same
- * vrc_frame_stats.rays / sum_complexity either way; iterations_not_executed is 0 with it.  (bench.py
- * reports the frame time with it as extra.every_ray_from_the_root.) */
+/* Measurement / A-B switch (off by default): on = 1 makes the frame kernel start EVERY ray at the
+ * root, as lsvo.hpp:60-72 does, instead of below it next to the previous hit / the camera
+ *  -- for every kind of frame (pinhole or lens, one bounce or the 2-bounce
+ * extension; the builds of the 8 x 8 lane map at 6 waves per SIMD, vrc_renderer_last_kernel ends in
+ * "_from_root").  Same image, same vrc_frame_stats.rays / sum_complexity either way;
+ * iterations_not_executed is 0 with it.  (bench.py reports the frame time with it as
+ * extra.every_ray_from_the_root.) */
 int vrc_renderer_set_walk_from_root(vrc_renderer *r, uint32_t on);
 /* The lane <-> (pixel, sample) map of the stage-synchronous kernel.  The reference's own map of
  * pixels to workers is the static 4 x 4 area grid of main.cpp:140-143; results do not depend on

@@ -129,7 +129,7 @@ int main(int argc, char** argv)
         std::vector<int32_t> peer_pids;
         if (rank == 0) for (pid_t k : kids) peer_pids.push_back((int32_t)k);
         else { peer_pids.push_back((int32_t)getppid()); for (pid_t k : kids) peer_pids.push_back((int32_t)k); }
-        pipe.waitAllWatched(flags, peer_pids, 60000);
+        pipe.waitAllWatched(flags, peer_pids, 30000);
         if (rank == 0) vrc_host::check(vrc_ipc_flag_set(flags, all_done, 1), "vrc_ipc_flag_set");   // every frame is complete: the writers may leave
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 

@@ -95,7 +95,7 @@ def test_a_dead_writer_ends_the_run_instead_of_hanging_it(built):
     t0 = time.monotonic()
     for rank in range(3):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE="3", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
-                   PW_DIE_RANK="1", PW_DIE_AT_FRAME="4", PW_FRAMES="12", PW_TIMEOUT_S="120")
+                   PW_DIE_RANK="1", PW_DIE_AT_FRAME="4", PW_FRAMES="12", PW_TIMEOUT_S="30")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "peer_write_worker.py")], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = []

@@ -176,17 +176,23 @@ def test_walk_from_root_switch(terrain7, textures):
     nodes, svo = terrain7
     L = vrc.capi.load()
     W, H, spp = 120, 68, 3
-    for aperture in (0.0,):                        # (frames with a lens or two bounces have no such build and ignore the switch)
+    for aperture, bounces, fused, name in ((0.0, 1, False, "k_render_sync_pinhole"), (0.4, 1, False, "k_render_sync"), (0.0, 2, False, "k_render_sync_pinhole2"),
+                                           (0.4, 2, True, "k_render_sync2_resolved"), (0.4, 1, True, "k_render_sync_resolved"), (0.0, 1, True, "k_render_sync_pinhole_resolved")):
         cam = vrc.make_camera((61.7, 9.3, 70.2), vrc.make_rotation(0.4, -0.6), fov=1.0, aperture=aperture, focal_length=40.0)
         out = []
         for on in (False, True):
             rc = vrc.RayCaster(svo, (W, H))
             rc.setLightPosition(vrc.reference_light(7))
-            rc.use_gi, rc.use_samples, rc.shadow_samples = True, True, 1
+            rc.use_gi, rc.use_samples, rc.shadow_samples, rc.gi_bounces = True, True, 1, bounces
             rc.setWalkFromRoot(on)
-            rc.renderFrame(cam, spp=spp)
-            out.append((rc.readAccum(), rc.stats()))
-            assert rc.lastKernel() == ("k_render_sync_pinhole_from_root" if on else "k_render_sync_pinhole")
+            if fused:                                  # (whole-spp units: the lens kernel's 7-wave build without the switch)
+                rc.setSampleChunk(spp)
+                rc.renderFrameResolved(cam, spp=spp)
+                out.append((rc.readImage(), rc.stats()))
+            else:
+                rc.renderFrame(cam, spp=spp)
+                out.append((rc.readAccum(), rc.stats()))
+            assert rc.lastKernel() == (name + "_from_root" if on else (name + "_w7" if name == "k_render_sync_resolved" else name)), rc.lastKernel()
         (a0, s0), (a1, s1) = out
         assert np.array_equal(a0, a1)
         assert (s0.rays, s0.sum_complexity, s0.primary_hits, s0.pixels) == (s1.rays, s1.sum_complexity, s1.primary_hits, s1.pixels)

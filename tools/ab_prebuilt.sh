@@ -8,7 +8,7 @@ BARGS=$1; shift
 mkdir -p $OUT
 for name in "$@"; do
   if [ "$name" = product ]; then unset VRC_LIB; else export VRC_LIB=$(pwd)/gpurun_variants/var_$name.so; fi
-  python3 bench.py --no-cpu-baseline --no-extras $BARGS > $OUT/$name.log 2>$OUT/$name.err
+  python3 bench.py --no-cpu-baseline --no-extras --blocks-min-seconds 0.5 $BARGS > $OUT/$name.log 2>$OUT/$name.err
   python3 - "$OUT/$name.log" "$name" <<'PY'
 import json, sys
 try:

@@ -11,7 +11,7 @@ mkdir -p $OUT
 export GPU_MAX_HW_QUEUES=8
 cd /tmp && export TMPDIR=/tmp
 run() { local name=$1; shift
-  timeout 400 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras "${BENCH_ARGS[@]}" > $OUT/$name.log 2>&1; }
+  timeout 400 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --blocks-min-seconds 0.5 "${BENCH_ARGS[@]}" > $OUT/$name.log 2>&1; }
 BENCH_ARGS=("$@")
 run fetch FETCH_SIZE
 run write WRITE_SIZE
