@@ -150,3 +150,70 @@ def test_round3_dist_path_logs_verified_the_gathered_frame():
         assert load3(name)["gathered_frames_equal_unsharded"] is True
     for name in ("cpp_peer_write_world2.json.log", "cpp_peer_write_world3.json.log"):
         assert load3(name)["composed_frames_equal_unsharded"] is True
+
+
+# ---- round 4: the parity bit, the CPU leg's stated host, the self-launched N > 1 lines, the world-8 rehearsals
+R4 = os.path.join(ROOT, "profiles", "r04")
+
+
+def load4(name):
+    with open(os.path.join(R4, name)) as f:
+        return json.loads(f.read().strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize("name", ["final_bench.json.log", "final_bench_steps20.json.log", "final_bench_c2.json.log", "final_bench_c4.json.log",
+                                  "final_bench_c5.json.log"])
+def test_round4_bench_line_contract(name):
+    d = load4(name)
+    for k, t in DRIVER_KEYS.items():
+        assert isinstance(d[k], t), k
+    assert d["vs_baseline"] is None and d["higher_is_better"] is True and d["unit"] == "Mrays/s" and d["n_gpus"] == 1
+    # the parity bit of the run itself: the timed renderer's frame 0 against the oracle's
+    assert d["config"]["frame_equals_oracle"] is True and "oracle/vrc_oracle.c" in d["config"]["frame_equals_oracle_is"]
+    assert d["config"]["library"].endswith("(the product)") and d["config"]["launched_by"] == "plain"
+    r = d["roofline"]
+    assert r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) < 0.01 * r["achieved"]
+    assert r["kernel_ms"] <= d["ms_per_step"] * 1.001 and r["achieved"] < r["peak"]
+    b = d["extra"]["ms_per_step_blocks"]
+    lo, med, hi = b["min_median_max"]
+    assert b["blocks"] >= 5 and lo <= med <= hi and abs(med - d["ms_per_step"]) < 1e-3
+    # the CPU leg says what the host gave it: the rate peaks at the container's quota because a team beyond it only gets throttled
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "Mrays/s"
+    h = c["host"]
+    assert h["cgroup_cpu_max"] and h["usable"] >= c["cores"]
+    if h["cgroup_quota_cores"]:
+        omp = [v for v in c["variants"] if v["decomp"] == "omp" and v["parity"]]
+        assert all(v["cpu_seconds_per_second"] <= h["cgroup_quota_cores"] * 1.1 for v in omp)
+        assert c["cores"] <= 2 * h["cgroup_quota_cores"]
+
+
+def test_round4_headline_line_carries_the_stamped_pmc_record():
+    d = load4("final_bench.json.log")
+    r = d["roofline"]
+    assert d["steps"] == 100 and d["config"]["frames_in_flight"] == 3 and r["kernel"] == "k_render_sync_pinhole_resolved"
+    assert r["traffic"] is not None and r["traffic"] < r["algorithmic_bytes_per_launch"] and r["bound"] == "valu_issue"
+    assert r["traffic_detail"]["profile"].startswith("profiles/r04/") and os.path.exists(os.path.join(ROOT, r["traffic_detail"]["profile"]))
+    # the timed region is one stretch of GPU work several seconds long (round-3 verdict item 5)
+    assert d["extra"]["ms_per_step_blocks"]["blocks"] * d["steps"] * d["ms_per_step"] * 1e-3 > 6.0
+    # a launch alone on the chip runs the samples-abreast kernel (the library's choice), and faster than round 3's 1.116 ms
+    one = d["extra"]["one_frame_in_flight"]
+    assert one["kernel"] == "k_render_sync_pinhole_s4" and one["ms_per_step"] < 1.11
+    import csv
+    with open(os.path.join(R4, "final_c3_kernel_stats.csv")) as f:
+        row = [x for x in csv.DictReader(f) if x["Name"].startswith("k_render")][0]
+    assert row["Name"] == r["kernel"] and abs(float(row["AverageNs"]) / 1e6 - r["kernel_ms_bracketed"]) < 0.05 * r["kernel_ms_bracketed"]
+
+
+def test_round4_self_launched_and_world8_lines():
+    for name, n in (("self_launch_gloo2_full.json.log", 2), ("self_launch_gloo2_root.json.log", 2), ("self_launch_gloo8_peer.json.log", 8)):
+        d = load4(name)
+        assert d["n_gpus"] == n and d["config"]["ranks_in_process_group"] == n and d["config"]["gathered_frame_equals_unsharded"] is True, name
+        assert d["config"]["launched_by"].startswith("bench.py itself") and d["config"]["distinct_gpus"] == 1
+    assert "direct peer writes" in load4("self_launch_gloo8_peer.json.log")["config"]["sharding"]
+    for w in (2, 3, 8):
+        assert load4(f"peer_write_world{w}.json.log")["composed_frame_equals_unsharded"] == [True] * 9
+        assert load4(f"cpp_peer_write_world{w}.json.log")["composed_frames_equal_unsharded"] is True
+    dead = load4("peer_write_dead_writer.json.log")
+    assert dead["exit_codes"] == [7, 5, 7] and dead["seconds"] < 80
