@@ -675,6 +675,20 @@ int render_impl(vrc_renderer* r, const vrc_camera* cam, const vrc_frame_params* 
             a.tail_tiles = (uint32_t)tt;
             units = (tiles - tt) * ((a.p.spp + c - 1) / c) + tt * cpt_tail;
         }
+#ifdef VRC_EXP_UNITS   // experiment builds only (tools/build_variant.py): "head chunk,tail chunk,tail units per wave" from the environment
+        if (const char* ev = getenv("VRC_EXP_UNITS")) {
+            unsigned ec = 0, ect = 0, etpw = 0;
+            if (sscanf(ev, "%u,%u,%u", &ec, &ect, &etpw) == 3 && ec >= 1 && ect >= 1 && a.lane_samples == 1u) {
+                c = ec > a.p.spp ? a.p.spp : ec;
+                a.sample_chunk = c < a.p.spp ? c : 0;
+                const uint32_t cpt_tail = (a.p.spp + ect - 1) / ect;
+                uint64_t tt = (uint64_t)etpw * waves / cpt_tail;
+                if (tt > tiles) tt = tiles;
+                a.sample_chunk_tail = ect; a.tail_tiles = (uint32_t)tt;
+                units = (tiles - tt) * ((a.p.spp + c - 1) / c) + tt * cpt_tail;
+            }
+        }
+#endif
         // the kernel numbers work units in 32 bits
         if (units > 0xfffffff0ull) return fail(VRC_ERR_INVALID, "vrc_render_frame: %llu work units (tiles x sample chunks) do not fit 32 bits; "
                                                "use fewer samples per call or a larger sample chunk", (unsigned long long)units);

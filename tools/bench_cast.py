@@ -49,6 +49,52 @@ def main():
                           "loop_iterations": steps, "algorithmic_GBps": round(alg / ms / 1e6, 1),
                           "hbm_frac": round(alg / ms / 1e6 / 8000.0, 4), "hit_rate": round(float((hits["hit"] != 0).mean()), 3)}))
 
+    # the chained form (vrc_cast_ray_chains): the camera rays as ray A, the shadow ray of every hit (raycaster.hpp:139,151-153)
+    # as ray B, started below the root next to A's hit -- against the same pairs cast as two independent batches
+    o, d = sets["camera 1920x1080 pitch -0.5 (row-major pixels)"]
+    n = o.shape[0]
+    to, td = torch.from_numpy(o).cuda(), torch.from_numpy(d).cuda()
+    out_a = torch.empty(n * 48, dtype=torch.uint8, device="cuda")
+    svo.castRaysDevice(n, to.data_ptr(), td.data_ptr(), out_a.data_ptr(), stream=stream)
+    torch.cuda.synchronize()
+    ha = np.frombuffer(out_a.cpu().numpy().tobytes(), dtype=vrc.HIT_DTYPE)
+    f = np.float32
+    inv = f(1.0) / f(1 << depth)
+    so = (ha["position"] + (ha["normal"] * inv) * f(0.001)).astype(f)
+    light = np.asarray(vrc.reference_light(depth), f)
+    sd = (light[None, :] - so).astype(f)
+    sd = (sd * (f(1.0) / np.sqrt((sd * sd).sum(axis=1, dtype=f)).astype(f))[:, None]).astype(f)
+    tso, tsd = torch.from_numpy(np.ascontiguousarray(so)).cuda(), torch.from_numpy(np.ascontiguousarray(sd)).cuda()
+    out_b = torch.empty(n * 48, dtype=torch.uint8, device="cuda")
+    skipped = torch.zeros(n, dtype=torch.int32, device="cuda")
+
+    def timed(fn, reps=20):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    ms_chain = timed(lambda: svo.castRayChainsDevice(n, to.data_ptr(), td.data_ptr(), tso.data_ptr(), tsd.data_ptr(), 0.0, out_a.data_ptr(),
+                                                     out_b.data_ptr(), skipped.data_ptr(), stream=stream))
+    hb = np.frombuffer(out_b.cpu().numpy().tobytes(), dtype=vrc.HIT_DTYPE).copy()
+    sk = int(skipped.sum().item())
+
+    def two():
+        svo.castRaysDevice(n, to.data_ptr(), td.data_ptr(), out_a.data_ptr(), stream=stream)
+        svo.castRaysDevice(n, tso.data_ptr(), tsd.data_ptr(), out_b.data_ptr(), stream=stream)
+    ms_two = timed(two)
+    hb2 = np.frombuffer(out_b.cpu().numpy().tobytes(), dtype=vrc.HIT_DTYPE)
+    print(json.dumps({"op": "vrc_cast_ray_chains", "rays": "camera rays + the shadow ray of every hit, started below the root", "pairs": n,
+                      "ms": round(ms_chain, 4), "Mrays_per_s": round(2 * n / ms_chain / 1e3, 1),
+                      "ms_as_two_vrc_cast_rays_batches": round(ms_two, 4), "shadow_iterations": int(hb["complexity"].sum()),
+                      "shadow_iterations_not_executed": sk, "chained_equals_independent": bool(hb.tobytes() == hb2.tobytes())}))
+
 
 if __name__ == "__main__":
     main()
