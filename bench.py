@@ -582,7 +582,8 @@ def main():
     def drain():
         if peers is not None:
             # streams that wait for flags are never synchronised blindly: a rank that died never writes its flag (watchdog:
-            # cpuvoxelraycaster_amd/dist.py PeerFrames.wait -> vrc_ipc_stream_wait; raises when a peer is gone)
+            # cpuvoxelraycaster_amd/dist.py PeerFrames.wait -> vrc_ipc_stream_wait; raises when a peer is gone, after every
+            # stream of this rank has drained with the release held)
             peers.wait([ts.cuda_stream for ts in tstreams])
         if dist_on and peers is None:
             torch.cuda.synchronize()                           # every frame stream has produced its shard

@@ -109,7 +109,12 @@ int main(int argc, char** argv)
         std::vector<void*> keep;                                // rank 0: a copy of every completed frame
         if (rank == 0) { keep.resize(frames); for (uint32_t i = 0; i < frames; ++i) HIPCHECK(hipMalloc(&keep[i], (size_t)W * H * 4)); }
 
+        // the watchdog's peers: rank 0 watches its children, a child its parent and the siblings forked before it
+        std::vector<int32_t> peer_pids;
+        if (rank == 0) for (pid_t k : kids) peer_pids.push_back((int32_t)k);
+        else { peer_pids.push_back((int32_t)getppid()); for (pid_t k : kids) peer_pids.push_back((int32_t)k); }
         const auto t0 = std::chrono::steady_clock::now();
+        try {
         for (uint32_t i = 0; i < frames; ++i) {
             const uint32_t slot = i % F;
             void* st = pipe.stream(slot);
@@ -125,11 +130,14 @@ int main(int argc, char** argv)
                 vrc_host::check(vrc_stream_write_flag(flags, consumed(slot), i + 1, st), "write consumed");
             }
         }
-        // the watchdog instead of a blind synchronize: rank 0 watches its children, a child its parent and its siblings
-        std::vector<int32_t> peer_pids;
-        if (rank == 0) for (pid_t k : kids) peer_pids.push_back((int32_t)k);
-        else { peer_pids.push_back((int32_t)getppid()); for (pid_t k : kids) peer_pids.push_back((int32_t)k); }
+        // the watchdog instead of a blind synchronize
         pipe.waitAllWatched(flags, peer_pids, 30000);
+        } catch (const std::exception&) {
+            // a peer is gone -- noticed by this rank's watchdog, or by another rank's while this one was still issuing frames
+            // (vrc_stream_wait_flag / _write_flag then fail at once): drain what is queued with the release held, then leave
+            try { pipe.waitAllWatched(flags, peer_pids, 10000); } catch (const std::exception&) {}
+            throw;
+        }
         if (rank == 0) vrc_host::check(vrc_ipc_flag_set(flags, all_done, 1), "vrc_ipc_flag_set");   // every frame is complete: the writers may leave
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 

@@ -55,28 +55,34 @@ def main():
     keep = [torch.zeros(H * W * 4, dtype=torch.uint8, device="cuda") for _ in range(frames)] if rank == 0 else None
     dist.barrier()
     t0 = time.perf_counter()
-    for i in range(frames):
-        rc, ts = rcs[i % in_flight], streams[i % in_flight]
-        with torch.cuda.stream(ts):
-            dbg("frame", i, "before_render")
-            if rank == int(os.environ.get("PW_DIE_RANK", "-1")) and i == int(os.environ.get("PW_DIE_AT_FRAME", "-1")):
-                os._exit(5)             # the failure test: this rank vanishes with frames in flight and flags unwritten
-            peers.before_render(i, ts.cuda_stream)
-            rc.frame_index = i * spp
-            rc.renderFrameResolved(cam, spp=spp, stream=ts.cuda_stream, row_block=vd.ROW_BLOCK, shard_index=rank, shard_count=world)
-            dbg("frame", i, "enqueued")
-            peers.after_render(i, ts.cuda_stream)
-            dbg("frame", i, "after_render done")
-            if rank == 0:
-                # "presenting" the frame = copying it out on the frame's stream, behind the waits for the writers' rows
-                keep[i].copy_(fb[i % in_flight], non_blocking=True)
-            peers.consumed_on(i, ts.cuda_stream)
-    dbg("all frames enqueued")
     try:
+        for i in range(frames):
+            rc, ts = rcs[i % in_flight], streams[i % in_flight]
+            with torch.cuda.stream(ts):
+                dbg("frame", i, "before_render")
+                if rank == int(os.environ.get("PW_DIE_RANK", "-1")) and i == int(os.environ.get("PW_DIE_AT_FRAME", "-1")):
+                    os._exit(5)             # the failure test: this rank vanishes with frames in flight and flags unwritten
+                peers.before_render(i, ts.cuda_stream)
+                rc.frame_index = i * spp
+                rc.renderFrameResolved(cam, spp=spp, stream=ts.cuda_stream, row_block=vd.ROW_BLOCK, shard_index=rank, shard_count=world)
+                dbg("frame", i, "enqueued")
+                peers.after_render(i, ts.cuda_stream)
+                dbg("frame", i, "after_render done")
+                if rank == 0:
+                    # "presenting" the frame = copying it out on the frame's stream, behind the waits for the writers' rows
+                    keep[i].copy_(fb[i % in_flight], non_blocking=True)
+                peers.consumed_on(i, ts.cuda_stream)
+        dbg("all frames enqueued")
         peers.wait([ts.cuda_stream for ts in streams], timeout_s=float(os.environ.get("PW_TIMEOUT_S", "60")))   # never a blind synchronize
     except vrc.capi.VrcError as e:
+        # a peer is gone (noticed by this rank's watchdog, or by another rank's while this one was still issuing frames):
+        # drain what is queued with the release held, then leave at once, non-zero -- no collective clean-up with a dead peer
+        try:
+            peers.wait([ts.cuda_stream for ts in streams], timeout_s=10.0)
+        except vrc.capi.VrcError:
+            pass
         print(json.dumps({"rank": rank, "error": str(e)}), flush=True)
-        os._exit(7)                     # no collective clean-up with a dead peer: leave at once, non-zero
+        os._exit(7)
     torch.cuda.synchronize()
     dbg("synchronized")
     dt = time.perf_counter() - t0

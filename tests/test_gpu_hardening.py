@@ -2,12 +2,15 @@
 out-of-bounds gather; scheduling knobs live in the renderer; the single-ray operator (Camera::getClosestPoint,
 camera_controller.hpp:56-60) goes through the scene's pinned slot and is thread-safe."""
 import ctypes as C
+import os
 import threading
 
 import numpy as np
 import pytest
 
 import oracle_lib as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -239,3 +242,54 @@ def test_host_batch_calls_from_several_threads(built, heights):
     for t in threads:
         t.join()
     assert not errors
+
+
+def test_frame_flag_segments_are_not_taken_from_a_live_owner(built, tmp_path):
+    """vrc_ipc_flags_open(create) used to unlink any segment of the same name.  Now: a segment whose owner is
+    alive is refused; the leftover of a process that died is replaced; an opener with another count is refused before the
+    mapping is touched (no SIGBUS); host-side flag stores and loads work; out-of-range indices are errors."""
+    import ctypes as C
+    import subprocess
+    import sys
+    import time
+    import cpuvoxelraycaster_amd as vrc
+    L = vrc.capi.load()
+    name = b"/vrc_test_flags_%d" % os.getpid()
+    child_src = (
+        "import sys, time, ctypes as C\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "import cpuvoxelraycaster_amd as vrc\n"
+        "L = vrc.capi.load(); f = C.c_void_p()\n"
+        "vrc.capi.check(L.vrc_ipc_flags_open(sys.argv[1].encode(), 16, 0, 1, C.byref(f)))\n"
+        "L.vrc_ipc_flag_set(f, 3, 77)\n"
+        "print('ready', flush=True)\n"
+        "if sys.argv[2] == 'stay': time.sleep(60)\n"
+        "import os; os._exit(0)\n")                            # no close: the segment stays behind, as after a crash
+    script = tmp_path / "owner.py"
+    script.write_text(child_src)
+    # (1) a live owner: refused, and the owner's segment is still there for an opener with the right count
+    p = subprocess.Popen([sys.executable, str(script), name.decode(), "stay"], stdout=subprocess.PIPE, text=True)
+    try:
+        assert p.stdout.readline().strip() == "ready"
+        f = C.c_void_p()
+        assert L.vrc_ipc_flags_open(name, 16, 0, 1, C.byref(f)) == -1 and b"in use by process" in L.vrc_last_error()
+        assert L.vrc_ipc_flags_open(name, 17, 0, 0, C.byref(f)) == -1            # made for another count
+        assert L.vrc_ipc_flags_open(name, 4096, 0, 0, C.byref(f)) == -1          # larger than the segment: refused, not mapped
+        vrc.capi.check(L.vrc_ipc_flags_open(name, 16, 0, 0, C.byref(f)))
+        assert L.vrc_ipc_flag_value(f, 3) == 77
+        assert L.vrc_ipc_flag_set(f, 16, 1) == -1 and L.vrc_ipc_flag_value(f, 16) == 0
+        vrc.capi.check(L.vrc_ipc_flags_close(f))
+    finally:
+        p.kill()
+        p.wait()
+    # (2) the owner is gone and left the segment behind: the next creator replaces it (zeros again)
+    f = C.c_void_p()
+    vrc.capi.check(L.vrc_ipc_flags_open(name, 16, 0, 1, C.byref(f)))
+    assert L.vrc_ipc_flag_value(f, 3) == 0
+    # (3) the watchdog on an idle stream is an immediate OK; with a pid that does not exist and work pending it would give up
+    st = C.c_void_p()
+    vrc.capi.check(L.vrc_stream_create(0, C.byref(st)))
+    assert L.vrc_ipc_stream_wait(f, st, None, 0, 1000) == 0
+    vrc.capi.check(L.vrc_stream_destroy(0, st))
+    vrc.capi.check(L.vrc_ipc_flags_close(f))
+    assert L.vrc_ipc_flags_open(name, 16, 0, 0, C.byref(f)) == -1                # closed by its owner: unlinked
