@@ -506,6 +506,7 @@ def main():
         # rank 0's F renderers own the framebuffers; the other ranks' renderers write their rows into them
         # (cpuvoxelraycaster_amd/dist.py PeerFrames: hipIpc-mapped framebuffers, frame flags in shared memory; no collective)
         peers = vdist.PeerFrames(rcs, local_rank, rank, world, dist.group.WORLD, "/vrc_bench_peer_%s" % os.environ.get("MASTER_PORT", "0"))
+        _PEER_EXCHANGE[:] = [peers, [ts.cuda_stream for ts in tstreams]]   # (a failing rank drains its streams before it leaves, see __main__)
 
     def finish_gather(slot):
         """wait (on the current stream) for the slot's outstanding all-gather and scatter it into the slot's frame"""
@@ -1056,5 +1057,18 @@ def main():
             sys.exit("bench.py: the timed renderer's frame 0 differs from the oracle's (config.frame_equals_oracle)")
 
 
+_PEER_EXCHANGE = []     # [PeerFrames, stream pointers] of a --gather peer run
+
+
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except BaseException:
+        # direct peer writes: a rank that fails must not leave with stream-ordered flag waits pending on the device -- the
+        # watchdog drains its streams with every wait released (and tells the other ranks to give up too)
+        if _PEER_EXCHANGE and not isinstance(sys.exc_info()[1], SystemExit):
+            try:
+                _PEER_EXCHANGE[0].wait(_PEER_EXCHANGE[1], timeout_s=10.0)
+            except Exception:                                     # noqa: BLE001
+                pass
+        raise
