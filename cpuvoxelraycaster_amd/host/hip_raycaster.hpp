@@ -130,6 +130,17 @@ public:
         return out;
     }
 
+    // pairs of casts as RayCaster::castRay chains them (raycaster.hpp:131 -> :153; :194 -> :198), device buffers: ray A, then
+    // ray B next to A's hit, started below the root as the frame kernels start their secondary rays (vrc_cast_ray_chains);
+    // hits_b[i] equals a cast of ray B alone.  Asynchronous on `stream`.
+    void castRayChainsDevice(uint64_t n, const float* org_a_dev, const float* dir_a_dev, const float* org_b_dev, const float* dir_b_dev,
+                             float ray_size_coef_b, vrc_hit* hits_a_dev, vrc_hit* hits_b_dev, uint32_t* not_executed_dev = nullptr,
+                             void* stream = nullptr) const
+    {
+        check(vrc_cast_ray_chains(scene_, n, org_a_dev, dir_a_dev, org_b_dev, dir_b_dev, ray_size_coef_b, hits_a_dev, hits_b_dev,
+                                  not_executed_dev, stream), "vrc_cast_ray_chains");
+    }
+
     // RayCaster's constructor loads the two 16 x 16 tables relative to the working directory (raycaster.hpp:53-54);
     // here the caller names the files
     void loadTextures(const std::string& top_bmp, const std::string& side_bmp)
