@@ -600,8 +600,9 @@ int render_impl(vrc_renderer* r, const vrc_camera* cam, const vrc_frame_params* 
     // The library's choice (lane_samples 0), measured on C3 / C4 and their 1/2 .. 1/8 shards (profiles/r04/ab_lane_map.txt,
     // shard_inflight_lane_map.txt): four abreast for a launch that has the chip to itself -- 3-6 % off a frame's latency: four
     // times the units, a quarter as long, no accumulator atomics -- and the pixel tiles for whole-spp units, which a caller asks
-    // for when frames overlap (there the hoisted set-up of the 8 x 8 map wins by 5 %: both maps issue the same number of VALU
-    // instructions, profiles/r04/pmcq_ns{1,4}.txt).
+    // for when frames overlap (there the 8 x 8 map wins by 5 %: both maps issue the same number of VALU instructions,
+    // profiles/r04/pmcq_ns{1,4}.txt, and four abreast has four times the queue pops and unit prologues for a wave to sit out,
+    // which a chip kept full by overlapping launches cannot hide -- DESIGN.md section 9).
     const bool caller_whole_spp = tuning.sample_chunk != 0u && tuning.sample_chunk >= a.p.spp;
     a.lane_samples = (can_s4 && (tuning.lane_samples == 4u || (tuning.lane_samples == 0u && !caller_whole_spp))) ? 4u : 1u;
     const uint32_t tw = a.lane_samples == 4u ? 4u : 8u;
