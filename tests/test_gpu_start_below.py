@@ -246,7 +246,7 @@ def test_constructed_margin_adversaries_through_the_kernel(built, heights, textu
     out_a = torch.zeros(n * 48, dtype=torch.uint8, device="cuda")
     out_b = torch.zeros(n * 48, dtype=torch.uint8, device="cuda")
     skipped = torch.zeros(n, dtype=torch.int32, device="cuda")
-    for coef in (0.0, 0.5):
+    for coef in (0.0, 0.5, 0.25):                  # (the operator takes any coefficient in [0, 0.5]; the frame kernels use 0 and 0.5)
         svo.castRayChainsDevice(n, d_oa.data_ptr(), d_da.data_ptr(), d_ob.data_ptr(), d_db.data_ptr(), coef, out_a.data_ptr(), out_b.data_ptr(),
                                 skipped.data_ptr())
         torch.cuda.synchronize()
