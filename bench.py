@@ -92,6 +92,13 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
+def pmc_key(config, world, inflight, whole_spp_units):
+    """The key of a workload's record in profiles/traffic.json: c3_n1 (frames in flight, the default command), c3_n1_inflight1
+    (one frame at a time, the library's own unit policy), c3_n1_inflight1_wholespp (the default command's kernel symbol one
+    launch at a time: `--inflight 1 --whole-spp 1 --fused 1 --lane-samples 1`)."""
+    return f"{config}_n{world}" + ("" if inflight > 1 else "_inflight1" + ("_wholespp" if whole_spp_units else ""))
+
+
 def pmc_record(key, kernel=None, fused=None, inflight=None):
     """The rocprofv3 PMC record of this workload from profiles/traffic.json (tools/pmc_roofline.sh +
     tools/update_traffic.py), or (None, reason) when there is none FOR THE KERNEL SOURCES OF THIS TREE, or when it was taken on
@@ -123,8 +130,9 @@ def cpu_baseline(cfg, nodes, textures, cam, light, budget_s=3.5):
       4x4x16     the reference's own decomposition: 16 threads, thread t owns area (t % 4, t / 4), x-outer / y-inner
                  (main.cpp:90-92,139-152), parity build (-O2 -ffp-contract=off) -- on OpenMP threads and, where
                  oracle/_ref/libref_swarm.so exists, on the reference's own swarm thread pool
-      omp        OpenMP dynamic rows on 16 / 32 / 64 / all usable host cores, parity build -- the fastest is the headline
-                 `value` (with its thread count as `cores`)
+      omp        OpenMP dynamic rows, parity build, on team sizes around the container's CPU quota (cgroup v2 cpu.max or v1
+                 cpu.cfs_quota_us: quota / 2, quota, 2 x, 4 x) or, where no quota is found, on 16 / 32 / 64 / half / all usable
+                 host cores -- the fastest is the headline `value` (with its thread count as `cores`)
       native     the same source built -O3 -march=native with FMA contraction allowed: NON-parity (its results may
                  differ from the reference's; it is only timed), at the fastest omp thread count
     each for ~budget_s seconds and at least one whole frame-sample."""
@@ -229,15 +237,15 @@ def cpu_baseline(cfg, nodes, textures, cam, light, budget_s=3.5):
     # around the quota, and each variant records the CPU seconds it got per wall second.  (Pinning threads -- OMP_PROC_BIND /
     # OMP_PLACES -- does not help under a quota, and binds the main thread to one core, which then is all that
     # sched_getaffinity() and the reference's swarm pool see: measured, 8.8 instead of 60 Mrays/s.)
-    quota_cores = None
-    try:
-        with open("/sys/fs/cgroup/cpu.max") as fh:
-            q, per = fh.read().split()[:2]
-            quota_cores = None if q == "max" else float(q) / float(per)
-    except (OSError, ValueError):
-        pass
+    quota_cores, quota_from = cgroup_cpu_quota()
     cap = usable if not quota_cores else min(usable, max(1, int(round(quota_cores))))
-    counts = sorted({c for c in (cap // 2, cap, 2 * cap, 4 * cap) if 1 <= c <= usable} or {usable})
+    if quota_cores:
+        cand = (cap // 2, cap, 2 * cap, 4 * cap)
+    else:
+        # no quota found (cgroup v1 without cfs limits, "max", or no cgroup files at all): nothing says where the rate peaks,
+        # so the fixed team sizes of rounds 1-3 stay in the set beside the usable count
+        cand = (16, 32, 64, usable // 2, usable)
+    counts = sorted({c for c in cand if 1 <= c <= usable} or {usable})
     best = None
     for c in counts:
         r, n, dt = run("omp", c)
@@ -253,7 +261,7 @@ def cpu_baseline(cfg, nodes, textures, cam, light, budget_s=3.5):
                     "parity": False, "value": round(r2 / dt2 / 1e6, 3), "frame_samples": n2, "seconds": round(dt2, 2)})
     # what the host gives this process: a cgroup CPU quota and the other tenants of the box decide how many of the `usable`
     # cores a thread team really gets -- cpu_seconds_per_second of a variant is the number of cores it was running on
-    host = {"os_cpu_count": os.cpu_count(), "usable": usable, "cgroup_quota_cores": quota_cores,
+    host = {"os_cpu_count": os.cpu_count(), "usable": usable, "cgroup_quota_cores": quota_cores, "cgroup_quota_from": quota_from,
             "scaling_note": ("the rate peaks at the container's CPU quota and falls beyond it (threads over the quota are throttled, not run): "
                              "cpu_seconds_per_second of each variant is the number of cores it actually ran on") if quota_cores else None}
     for name, path in (("cgroup_cpu_max", "/sys/fs/cgroup/cpu.max"), ("loadavg", "/proc/loadavg")):
@@ -270,14 +278,42 @@ def cpu_baseline(cfg, nodes, textures, cam, light, budget_s=3.5):
             "variants": out}
 
 
+def cgroup_cpu_quota(root="/sys/fs/cgroup"):
+    """(cores, where it was read) of this container's CFS quota, or (None, None): cgroup v2's cpu.max ("<quota> <period>" or
+    "max <period>"), else cgroup v1's cpu.cfs_quota_us / cpu.cfs_period_us (-1 = no limit)."""
+    try:
+        with open(os.path.join(root, "cpu.max")) as fh:
+            q, per = fh.read().split()[:2]
+        return (None, None) if q == "max" else (float(q) / float(per), "cgroup v2 cpu.max")
+    except (OSError, ValueError):
+        pass
+    for d in ("cpu", "cpu,cpuacct", ""):
+        try:
+            with open(os.path.join(root, d, "cpu.cfs_quota_us")) as fh:
+                q = float(fh.read().strip())
+            with open(os.path.join(root, d, "cpu.cfs_period_us")) as fh:
+                per = float(fh.read().strip())
+            return (None, None) if q <= 0 or per <= 0 else (q / per, "cgroup v1 cpu.cfs_quota_us / cpu.cfs_period_us")
+        except (OSError, ValueError):
+            continue
+    return None, None
+
+
 def rank_environments(n, base_env, port):
-    """The environment of each of the N ranks of one node -- what torch.distributed.run would set for them."""
+    """The environment of each of the N ranks of one node -- what torch.distributed.run would set for them.
+
+    HSA_ENABLE_IPC_MODE_LEGACY: whatever the launching environment says is passed on untouched.  Only where it says nothing
+    do the ranks get "0" (dmabuf IPC), for EVERY exchange form: on this pool's host driver legacy-mode IPC handles do not
+    exist, and without the variable both hipIpcGetMemHandle (--gather peer) and RCCL's own intra-node P2P set-up (--gather
+    root / all) fail with "invalid argument" (the image exports it for that reason).
+    VRC_KEEP_IPC_MODE=1 leaves an unset variable unset.  The value the ranks ran with is in the line: config.exchange."""
     envs = []
     for r in range(n):
         e = dict(base_env)
         e.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
-                  "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "VRC_BENCH_LAUNCHED_BY": str(os.getpid()),
-                  "HSA_ENABLE_IPC_MODE_LEGACY": base_env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+                  "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "VRC_BENCH_LAUNCHED_BY": str(os.getpid())})
+        if "HSA_ENABLE_IPC_MODE_LEGACY" not in base_env and base_env.get("VRC_KEEP_IPC_MODE") != "1":
+            e["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
         envs.append(e)
     return envs
 
@@ -305,7 +341,7 @@ def launch_ranks(n, argv, popen=None, grace_s=20.0):
     envs = rank_environments(n, os.environ, port)
     if os.environ.get("VRC_BENCH_LAUNCH_DRYRUN") == "1":         # tests/test_bench_launch.py: the plan, nothing started
         keys = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "HSA_ENABLE_IPC_MODE_LEGACY")
-        print(json.dumps({"argv": [sys.executable, os.path.abspath(__file__)] + list(argv), "ranks": [{k: e[k] for k in keys} for e in envs],
+        print(json.dumps({"argv": [sys.executable, os.path.abspath(__file__)] + list(argv), "ranks": [{k: e.get(k) for k in keys} for e in envs],
                           "torch_imported": "torch" in sys.modules, "modules_touching_gpu": sorted(m for m in sys.modules if m.split(".")[0] in ("torch", "cpuvoxelraycaster_amd", "ctypes"))}))
         return 0
     procs = []
@@ -362,6 +398,25 @@ def oracle_frame(cfg, nodes, textures, cam, light, threads):
     return O.samples_to_image(acc), rays, sumc
 
 
+def exchange_facts(torch, dist, backend, world):
+    """What the N > 1 exchange ran on, for the bench line: RCCL's version, the GPUs of the node and which of them can reach
+    which directly (hipDeviceCanAccessPeer: xGMI links between the ranks' devices), and the IPC mode of the run."""
+    facts = {"backend": backend, "world": world, "gpus_on_node": torch.cuda.device_count(),
+             "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
+             "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")}
+    try:
+        facts["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception as e:                                       # noqa: BLE001
+        facts["rccl_version"] = f"unavailable: {e!r}"[:120]
+    try:
+        n = torch.cuda.device_count()
+        facts["device_can_access_peer"] = [[(1 if i == j else int(torch.cuda.can_device_access_peer(i, j))) for j in range(n)] for i in range(n)]
+        facts["device_names"] = sorted({torch.cuda.get_device_name(i) for i in range(n)})
+    except Exception as e:                                       # noqa: BLE001
+        facts["device_can_access_peer"] = f"unavailable: {e!r}"[:120]
+    return facts
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -374,6 +429,8 @@ def main():
                     help="keep timing blocks until this much has been timed (max 4096 blocks): the timed region is one contiguous stretch of GPU "
                          "work several seconds long, so that an outside sampler of GPU activity sees it (round-3 verdict item 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-oracle-frame", action="store_true",
+                    help="skip config.frame_equals_oracle (frame 0 of the timed renderers -- at N > 1 the gathered frame 0 -- against the oracle's)")
     ap.add_argument("--inflight", type=int, default=0,
                     help="frames in flight per GPU (renderers / streams used round-robin); 1 = one stream, each frame starts "
                          "when the previous one has ended; 0 = default: 3")
@@ -387,6 +444,10 @@ def main():
                     help="resolve + pack + reset inside the frame kernel (vrc_render_frame_resolved) instead of a second kernel; "
                          "auto = whenever frames overlap (whole-spp work units: the fused path then resolves from registers, "
                          "never slower, 1 % faster on short shards; tools/shard_inflight.py, tools/resolve_cost.py)")
+    ap.add_argument("--whole-spp", default="auto", choices=["auto", "0", "1"],
+                    help="work unit of the frame kernel = a tile's WHOLE sample set (vrc_renderer_set_sample_chunk(spp)); auto = whenever "
+                         "frames overlap (--inflight > 1).  `--inflight 1 --whole-spp 1 --fused 1 --lane-samples 1` runs the timed "
+                         "region's kernel symbol one launch at a time: the form rocprofv3 --stats can time cleanly")
     ap.add_argument("--lane-samples", type=int, default=0, choices=[0, 1, 4],
                     help="lane <-> (pixel, sample) map of the frame kernel (vrc_renderer_set_lane_samples): 1 = 8 x 8 pixels per wave, "
                          "4 = 4 x 4 pixels x 4 samples abreast, 0 = the library's choice")
@@ -472,7 +533,7 @@ def main():
     # with frames overlapping, a launch's tail is covered by the next frame's launch: work units of ALL the samples of a tile
     # (one primary / shadow set-up per tile, no atomics, resolved from registers by the fused path) beat the short units the
     # library picks for a launch that has the chip to itself (tools/shard_inflight.py)
-    whole_spp_units = F > 1
+    whole_spp_units = F > 1 if args.whole_spp == "auto" else args.whole_spp == "1"
     fused = whole_spp_units if args.fused == "auto" else args.fused == "1"
 
     def make_renderer(whole=None):
@@ -522,7 +583,7 @@ def main():
                                            vrc.capi.ptr(full[slot].data_ptr()),
                                            vrc.capi.ptr(torch.cuda.current_stream().cuda_stream)))
 
-    def step(timed):
+    def step(timed, frame_override=None):
         # one frame = render (spp samples per pixel into the accumulators) + one pass that resolves this rank's
         # rows to RGBA8 (straight into the packed shard buffer for N > 1) and clears their accumulators for the
         # next frame (vrc_resolve_shard = samples_to_image + pack_shard + reset_samples)
@@ -535,7 +596,9 @@ def main():
                 peers.before_render(i, stream)                 # rank 0 has consumed the frame this framebuffer held
             elif dist_on:
                 finish_gather(slot)                            # the frame that used this slot's buffers last
-            rc.frame_index = i * spp
+            # (frame_override: which frame's samples are rendered -- the slot / flag sequence still follows i; the N > 1 parity bit
+            # renders frame 0 again through the exchange after the timed region)
+            rc.frame_index = (i if frame_override is None else frame_override) * spp
             use_ev = timed
             if use_ev:
                 e0 = torch.cuda.Event(enable_timing=True)
@@ -616,21 +679,24 @@ def main():
         for _ in range(args.steps):
             step(True)
         enq_us = (time.perf_counter() - t0) / args.steps * 1e6   # host time to issue a frame (no waiting on the GPU unless a slot is busy)
+        t_dr = time.perf_counter()
         drain()                                                # the last frames' gathers are inside the timed region
+        drain_ms = (time.perf_counter() - t_dr) * 1e3           # this rank's host wait for its own streams / exchanges to empty
         if dist_on:
             dist.barrier()
             torch.cuda.synchronize()
-        el = time.perf_counter() - t0
+        el = el_local = time.perf_counter() - t0
         if dist_on:                                            # the slowest rank's clock decides, block by block
             t = torch.tensor([el], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
-        blocks.append((el, enq_us, [r.stats(stream=tstreams[0].cuda_stream) for r in rcs], list(ev_pairs)))
+        el_mine = time.perf_counter() - t0 if not dist_on else el_local
+        blocks.append((el, enq_us, [r.stats(stream=tstreams[0].cuda_stream) for r in rcs], list(ev_pairs), drain_ms, el_mine))
         if len(blocks) == 1 and args.blocks_min_seconds > 0:   # from the first block's (rank-agreed) time: the same count on every rank
             n_blocks = min(4096, max(n_blocks, int(args.blocks_min_seconds / max(el, 1e-6)) + 1))
     order = sorted(range(len(blocks)), key=lambda k: blocks[k][0])
     med = order[len(order) // 2]                               # the median block is the one reported
-    elapsed, host_enqueue_us, sts, med_events = blocks[med]
+    elapsed, host_enqueue_us, sts, med_events, med_drain_ms, med_elapsed_mine = blocks[med]
     del ev_pairs[:]
     ev_pairs.extend(med_events)
     block_ms = [b[0] / args.steps * 1e3 for b in blocks]
@@ -672,6 +738,24 @@ def main():
         torch.cuda.synchronize()
         got = rcs[state["last_slot"]].readImage(stream) if peers is not None else full[state["last_slot"]].cpu().numpy().reshape(H, W, 4)
         verified = bool(np.array_equal(got, ref.readImage(stream)))
+
+    # the parity bit at N > 1 (round-4 verdict, Next 2a): frame 0 once more THROUGH THE EXCHANGE -- every rank renders its rows of
+    # frame 0 with the timed renderers and settings, the shards meet the timed way -- and rank 0 compares the gathered frame and
+    # the ranks' summed counters with the oracle's frame 0 (below, where the line is put together)
+    frame0 = None
+    if dist_on and world > 1 and not args.no_oracle_frame:
+        for r in rcs:
+            r.stats(reset=True, stream=tstreams[0].cuda_stream)
+        dist.barrier()
+        step(False, frame_override=0)
+        drain()
+        c0 = torch.tensor([sum(r.stats(stream=tstreams[0].cuda_stream).rays for r in rcs),
+                           sum(r.stats(stream=tstreams[0].cuda_stream).sum_complexity for r in rcs)], dtype=torch.int64, device="cuda")
+        dist.all_reduce(c0, op=dist.ReduceOp.SUM)
+        if rank == 0:
+            got0 = rcs[state["last_slot"]].readImage(stream) if peers is not None else full[state["last_slot"]].cpu().numpy().reshape(H, W, 4)
+            frame0 = (got0.copy(), int(c0[0].item()), int(c0[1].item()))
+        dist.barrier()                                         # (peer writes: nobody overwrites rank 0's framebuffer before it is read)
 
     # extra, N > 1 on RCCL: the same frames with the OTHER exchange form (all-gather <-> gather to rank 0), so that one
     # driver run records both (not part of `value`)
@@ -735,6 +819,18 @@ def main():
             r.stats(reset=True, stream=tstreams[0].cuda_stream)
         if peers is not None:                                  # those frames went to rank 0's framebuffers without flags:
             dist.barrier()                                     # nobody reads them, but keep the ranks together
+    # N > 1: what each rank saw, so that a poor scaling curve explains itself (round-4 verdict, Next 2c)
+    per_rank = None
+    if dist_on:
+        mine_diag = {"rank": rank, "device": local_rank, "kernel_ms": round(kernel_ms, 4),
+                     "kernel_ms_render_only": round(render_only_ms, 4) if render_only_ms is not None else None,
+                     "exchange_ms_per_step": (round(kernel_ms - render_only_ms, 4) if render_only_ms is not None else None),
+                     "drain_wait_ms_per_block": round(med_drain_ms, 3), "block_ms_own_clock": round(med_elapsed_mine * 1e3, 3),
+                     "host_enqueue_us_per_step": round(host_enqueue_us, 1),
+                     "rays_per_frame": st.rays // args.steps, "pid": os.getpid()}
+        gathered_diag = [None] * dist.get_world_size()
+        dist.all_gather_object(gathered_diag, mine_diag)
+        per_rank = gathered_diag
     # untimed extra, N = 1 only: BASELINE config 3's text says "GI 2 bounces"; the reference has ONE indirect bounce
     # (RayContext::gi_bounce is never read), which is what `value` measures -- the 2-bounce EXTENSION
     # (recursive getGlobalIllumination at the GI hit, defined by the oracle) is reported beside it
@@ -775,6 +871,46 @@ def main():
             "kernel": rc1.lastKernel(),
             "note": "--inflight 1: one stream, each frame starts when the previous one has ended; the library's automatic work-unit "
                     "policy, resolve as a second kernel; median block of `blocks` (min / median / max in ms_per_step_blocks)"}
+    if rank == 0 and world == 1 and not dist_on and not args.no_extras and F > 1:
+        # the TIMED kernel symbol one launch at a time (round-4 verdict, Next 1): same unit policy, resolve and lane map as the
+        # timed renderers, one stream, events around every launch -- the duration rocprofv3 --stats can reproduce
+        # (`--inflight 1 --whole-spp 1 --fused 1 --lane-samples 1`, profiles/traffic.json[<config>_n1_inflight1_wholespp])
+        rca = make_renderer()
+        if not args.lane_samples:
+            rca.setLaneSamples(1)                                 # (whole-spp units already make the library pick the 8 x 8 map)
+        ts = tstreams[0]
+        na = max(10, min(args.steps, 50))
+        runs_a = []
+        with torch.cuda.stream(ts):
+            def frame_a(i):
+                rca.frame_index = i * spp
+                ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ea.record(ts)
+                if fused:
+                    rca.renderFrameResolved(cam, spp=spp, stream=ts.cuda_stream)
+                else:
+                    rca.renderFrame(cam, spp=spp, stream=ts.cuda_stream)
+                eb.record(ts)
+                if not fused:
+                    rca.resolveShard(reset=True, stream=ts.cuda_stream)
+                return ea, eb
+            for i in range(3):
+                frame_a(i)
+            for blk in range(max(3, args.blocks)):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                evs = [frame_a(3 + blk * na + i) for i in range(na)]
+                torch.cuda.synchronize()
+                runs_a.append(((time.perf_counter() - t1) / na * 1e3, sum(a.elapsed_time(b) for a, b in evs) / len(evs)))
+        runs_a.sort(key=lambda r: r[1])
+        ma = runs_a[len(runs_a) // 2]
+        extras["timed_symbol_alone"] = {
+            "kernel": rca.lastKernel(), "kernel_ms": round(ma[1], 4), "ms_per_step": round(ma[0], 4), "steps": na, "blocks": len(runs_a),
+            "kernel_ms_blocks": [round(runs_a[0][1], 4), round(ma[1], 4), round(runs_a[-1][1], 4)],
+            "note": "the timed region's kernel symbol and unit policy, one launch at a time on one stream (HIP events around each launch, "
+                    "median block); this is what `rocprofv3 --stats -- python3 bench.py --inflight 1 --whole-spp 1 --fused 1 --lane-samples 1` "
+                    "reports as the symbol's average duration"}
+
     if rank == 0 and world == 1 and not dist_on and not args.no_extras and args.config == "c3":
         # the same way as the timed region: F renderers / streams round-robin, same unit policy, same resolve
         rcs2 = [make_renderer() for _ in range(F)]
@@ -893,7 +1029,7 @@ def main():
         # passes recorded in profiles/traffic.json -- only when that record was taken on THIS tree's kernel sources
         # (the stage-synchronous kernel has a specialisation for the pinhole camera, see csrc/vrc_kernels.hip launch_render)
         sync_kernel_name = rcs[0].lastKernel()       # the build the library chose for this kind of launch (vrc_renderer_last_kernel)
-        rec, why = pmc_record(f"{args.config}_n{world}" + ("" if F > 1 else "_inflight1"), kernel=sync_kernel_name, fused=fused, inflight=F)
+        rec, why = pmc_record(pmc_key(args.config, world, F, whole_spp_units), kernel=sync_kernel_name, fused=fused, inflight=F)
         traffic = rec["traffic_bytes"] if rec else None
         roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
@@ -913,6 +1049,25 @@ def main():
                 "achieved_is": "ALGORITHMIC bytes (SURVEY 8d: 8 B per walk-loop iteration EXECUTED + 32 B per pixel) / kernel time -- nominal by "
                                "construction: the tree is L1/L2-resident, see traffic_frac_of_peak, and the binding limit is VALU "
                                "instruction issue, see issue"}
+        if "timed_symbol_alone" in extras:
+            ka = extras["timed_symbol_alone"]["kernel_ms"]
+            roof["kernel_ms_alone"] = ka
+            roof["frac_alone"] = round(alg_bytes / (ka * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5)
+            roof["kernel_ms_alone_is"] = ("the same kernel symbol, work units and resolve as the timed region, ONE launch at a time (HIP events around "
+                                          "each launch, measured in this run right after the timed region: extra.timed_symbol_alone); frac_alone = "
+                                          "algorithmic_bytes_per_launch / kernel_ms_alone / peak.  kernel_ms / frac are per frame PERIOD with "
+                                          f"{F} launches sharing the chip")
+            rec_a, why_a = pmc_record(pmc_key(args.config, world, 1, True), kernel=extras["timed_symbol_alone"]["kernel"], fused=fused, inflight=1)
+            if rec_a and rec_a.get("profiled_kernel_ms"):
+                pa = rec_a["profiled_kernel_ms"]
+                roof["kernel_ms_alone_rocprof"] = {
+                    "average_ms": pa, "profile": rec_a["profile"].replace("_pmc.txt", "_kernel_stats.csv"), "pmc": rec_a["profile"],
+                    "frac_alone": round(alg_bytes / (pa * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
+                    "agrees_with_kernel_ms_alone_within_3pct": bool(abs(pa / ka - 1.0) <= 0.03),
+                    "note": "rocprofv3 --kernel-trace --stats average duration of this symbol under `bench.py --inflight 1 --whole-spp 1 --fused 1 "
+                            "--lane-samples 1` on these kernel sources (stamped by hash in profiles/traffic.json)"}
+            else:
+                roof["kernel_ms_alone_rocprof"] = {"average_ms": None, "note": why_a}
         if rec:
             roof["traffic_frac_of_peak"] = round(traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5)
             roof["traffic_detail"] = {k: rec[k] for k in ("fetch_bytes", "write_bytes", "profile", "commit", "profiled_kernel_ms") if k in rec}
@@ -990,15 +1145,22 @@ def main():
                        "loop_iterations_per_frame": steps_sum // args.steps,
                        "camera_pitch": args.pitch, "lsvo_nodes": svo.n_nodes,
                        "lsvo_gpu_build_ms": round(svo.build_ms, 3), "lsvo_gpu_build_call_ms": round(build_call_ms, 3),
+                       "ms_per_step_is": (f"frame PERIOD with {F} frames in flight (all `steps` frames complete inside the timed region); the LATENCY of one "
+                                          "frame, rendered alone, is extra.one_frame_in_flight.ms_per_step" if F > 1 else
+                                          "frame latency = period: one frame at a time on one stream"),
                        "frames_in_flight": F, "whole_spp_work_units": whole_spp_units, "resolve_fused_into_frame_kernel": fused, "host_enqueue_us_per_step": round(host_enqueue_us, 1), "sharding": f"{ROW_BLOCK}-row blocks round-robin over {world} GPU(s)"
                        + ((", direct peer writes into rank 0's framebuffers (hipIpc), no collective" if args.gather == "peer" else
-                          f", RCCL {'gather to rank 0' if args.gather == 'root' else 'all-gather'} of RGBA8 shards") if dist_on else ""),
+                          (f", RCCL {'gather to rank 0' if args.gather == 'root' else 'all-gather'} of RGBA8 shards" if backend == "nccl" else
+                           f", {backend} all_gather of RGBA8 shards staged through the host (REHEARSAL of the N > 1 control flow"
+                           + (": the ranks share a GPU" if ranks_share_gpus else "") + "; the real exchange is RCCL)")) if dist_on else ""),
                        "ranks_in_process_group": (dist.get_world_size() if dist_on else 1),
                        "launched_by": ("bench.py itself (launch_ranks)" if os.environ.get("VRC_BENCH_LAUNCHED_BY") else
                                        "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "plain"),
                        "distinct_gpus": min(world, torch.cuda.device_count()),
                        "library": (os.environ.get("VRC_LIB") or "cpuvoxelraycaster_amd/libvrc_hip.so (the product)"),
                        "exchange_backend": (backend if dist_on else None),
+                       "exchange": exchange_facts(torch, dist, backend, world) if dist_on else None,
+                       "per_rank": per_rank,
                        "gathered_frame_equals_unsharded": verified,
                        "frame_equals_oracle": None},
             "roofline": roof,
@@ -1013,7 +1175,23 @@ def main():
                                                 "roofline are those of the median block"}
         if extras:
             out["extra"] = extras
-        if world == 1 and not args.no_cpu_baseline:
+        if frame0 is not None:
+            # the parity bit at N > 1: the GATHERED frame 0 and the ranks' summed counters against the oracle's frame 0
+            try:
+                usable_cores = len(os.sched_getaffinity(0))
+            except AttributeError:
+                usable_cores = os.cpu_count() or 1
+            t_or = time.perf_counter()
+            ref_img, ref_rays, ref_sumc = oracle_frame(cfg, svo.downloadNodes(), textures, cam, light, min(64, usable_cores))
+            got0, rays0, sumc0 = frame0
+            frame_ok = bool(np.array_equal(got0, ref_img)) and (rays0, sumc0) == (ref_rays, ref_sumc)
+            out["config"]["frame_equals_oracle"] = frame_ok
+            out["config"]["frame_equals_oracle_is"] = (
+                f"frame 0 ({spp} samples of all {W * H} pixels) rendered once more after the timed region by the {world} ranks' timed renderers "
+                f"({sync_kernel_name}), each its own row blocks, gathered the timed way ({out['config']['sharding']}) vs oracle/vrc_oracle.c: the "
+                f"gathered RGBA8 image bit for bit, rays summed over ranks {rays0} vs {ref_rays}, loop iterations {sumc0} vs {ref_sumc}; oracle time "
+                f"{time.perf_counter() - t_or:.1f} s on rank 0")
+        if world == 1 and not args.no_cpu_baseline and not args.no_oracle_frame:
             # the parity bit of THIS run (round-3 verdict item 4): frame 0 once more on a renderer set up like the timed ones
             # (same unit policy, same resolve, same lane map) against the oracle's frame 0 -- image, rays, loop iterations
             host_nodes = svo.downloadNodes()
@@ -1038,7 +1216,8 @@ def main():
                 f"frame 0 ({spp} samples of all {W * H} pixels) rendered by {chk.lastKernel()} on a renderer configured like the timed ones vs "
                 f"oracle/vrc_oracle.c: resolved RGBA8 image bit for bit, rays {got_st.rays} vs {ref_rays}, loop iterations {got_st.sum_complexity} vs "
                 f"{ref_sumc}; oracle time {time.perf_counter() - t_or:.1f} s")
-            out["cpu_baseline"] = cpu_baseline(cfg, host_nodes, textures, cam, light)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, svo.downloadNodes(), textures, cam, light)
     if dist_on:
         dist.barrier()
     if peers is not None:

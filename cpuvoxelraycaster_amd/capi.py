@@ -112,6 +112,7 @@ SYMBOLS = {
     "vrc_renderer_set_image_target": (_int, [_vp, _vp]),
     "vrc_ipc_flags_open": (_int, [C.c_char_p, _u32, _int, _int, C.POINTER(_vp)]),
     "vrc_ipc_flags_close": (_int, [_vp]),
+    "vrc_ipc_flags_unlink": (_int, [_vp]),
     "vrc_ipc_stream_wait": (_int, [_vp, _vp, _vp, _u32, _u32]),
     "vrc_ipc_flag_set": (_int, [_vp, _u32, _u32]),
     "vrc_stream_write_flag": (_int, [_vp, _u32, _u32, _vp]),

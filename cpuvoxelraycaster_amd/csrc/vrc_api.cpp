@@ -784,6 +784,7 @@ struct vrc_ipc_flags {
     uint32_t* host = nullptr;     // the mapping
     uint32_t* dev = nullptr;      // the same words as the device sees them
     bool owner = false;
+    bool unlinked = false;        // the creator has removed the name already (vrc_ipc_flags_unlink)
     char name[96] = {0};
 };
 // the segment: `count` flags, then four words of header {magic, owner's pid, count, given up}
@@ -882,28 +883,45 @@ extern "C" int vrc_ipc_flags_open(const char* name, uint32_t count, int device, 
 
 static bool flags_given_up(const vrc_ipc_flags* f) { return __atomic_load_n(f->host + f->count + FLAGS_HDR_GIVEN_UP, __ATOMIC_ACQUIRE) != 0u; }
 
-// the watchdog of a stream that waits for flags (include/vrc.h)
+// the watchdog of a stream that waits for flags (include/vrc.h).  timeout_ms is an INACTIVITY limit: the clock starts again
+// whenever any flag of the segment changes (a frame of some rank completed), so a healthy exchange that is still draining a
+// long queue is never declared dead -- only one on which nothing has moved for timeout_ms.
 extern "C" int vrc_ipc_stream_wait(vrc_ipc_flags* f, void* stream, const int32_t* pids, uint32_t n_pids, uint32_t timeout_ms)
 {
     if (!f || (n_pids && !pids)) return fail(VRC_ERR_INVALID, "vrc_ipc_stream_wait: bad argument");
     HIP_TRY(hipSetDevice(f->device));
-    const auto t0 = std::chrono::steady_clock::now();
+    auto flags_digest = [f]() {                                    // changes whenever a flag does (flags only ever grow)
+        uint64_t d = 0;
+        for (uint32_t i = 0; i < f->count; ++i) d += __atomic_load_n(f->host + i, __ATOMIC_RELAXED);
+        return d;
+    };
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto t_progress = t_begin;
+    uint64_t digest = flags_digest();
     const char* why = nullptr;
     int32_t who = 0;
-    uint32_t spins = 0;
+    uint32_t polls = 0;
     for (;;) {
         const hipError_t q = hipStreamQuery((hipStream_t)stream);
         if (q == hipSuccess) return flags_given_up(f) ? fail(VRC_ERR_PEER, "vrc_ipc_stream_wait: the exchange was given up (a peer died or timed out)") : VRC_OK;
         if (q != hipErrorNotReady) return fail(VRC_ERR_HIP, "vrc_ipc_stream_wait: hipStreamQuery: %s", hipGetErrorString(q));
         if (flags_given_up(f)) { why = "another process gave the exchange up"; break; }
-        if ((++spins & 63u) == 0u) {                               // the peers, every few milliseconds
-            for (uint32_t k = 0; k < n_pids && !why; ++k)
-                if (process_gone(pids[k])) { why = "a peer process is gone"; who = pids[k]; }
-            if (why) break;
-            const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
-            if (timeout_ms && ms >= (long long)timeout_ms) { why = "timed out"; break; }
+        const auto now = std::chrono::steady_clock::now();
+        const long long us = std::chrono::duration_cast<std::chrono::microseconds>(now - t_begin).count();
+        // the caller usually sits in a timed region: the first 3 ms are polled without sleeping (a stream that is nearly
+        // drained ends within a poll, not within a sleep), then 50 us naps, 500 us ones after 100 ms
+        if ((++polls & 63u) == 0u || us >= 3000) {
+            const uint64_t d = flags_digest();
+            if (d != digest) { digest = d; t_progress = now; }
+            if (us >= 3000 || (polls & 1023u) == 0u) {
+                for (uint32_t k = 0; k < n_pids && !why; ++k)
+                    if (process_gone(pids[k])) { why = "a peer process is gone"; who = pids[k]; }
+                if (why) break;
+            }
+            const auto idle_ms = std::chrono::duration_cast<std::chrono::milliseconds>(now - t_progress).count();
+            if (timeout_ms && idle_ms >= (long long)timeout_ms) { why = "no flag moved within the timeout"; break; }
         }
-        std::this_thread::sleep_for(std::chrono::microseconds(spins < 2000u ? 50 : 500));
+        if (us >= 3000) std::this_thread::sleep_for(std::chrono::microseconds(us < 100000 ? 50 : 500));
     }
     // give up for everyone: mark the segment, then release every wait on its flags (>= comparisons: the largest value passes all).
     // The release has to be HELD while the stream drains: the stream-ordered flag writes still queued behind the waits (this
@@ -921,13 +939,25 @@ extern "C" int vrc_ipc_stream_wait(vrc_ipc_flags* f, void* stream, const int32_t
     return fail(VRC_ERR_PEER, "vrc_ipc_stream_wait: %s (pid %d); every wait on %s was released, frames after this are not valid", why, (int)who, f->name);
 }
 
+// Once every process of the run has opened the segment its NAME is no longer needed: the creator removes it (the mappings stay
+// valid until the last process unmaps), so a run that is killed later leaves nothing behind in /dev/shm.
+extern "C" int vrc_ipc_flags_unlink(vrc_ipc_flags* f)
+{
+    if (!f) return fail(VRC_ERR_INVALID, "vrc_ipc_flags_unlink: null argument");
+    if (!f->owner) return fail(VRC_ERR_INVALID, "vrc_ipc_flags_unlink: only the process that created %s removes its name", f->name);
+    if (!f->unlinked && shm_unlink(f->name) != 0 && errno != ENOENT)
+        return fail(VRC_ERR_INVALID, "vrc_ipc_flags_unlink: shm_unlink(%s): %s", f->name, strerror(errno));
+    f->unlinked = true;
+    return VRC_OK;
+}
+
 extern "C" int vrc_ipc_flags_close(vrc_ipc_flags* f)
 {
     if (!f) return VRC_OK;
     (void)hipSetDevice(f->device);
     (void)hipHostUnregister(f->host);
     munmap(f->host, f->bytes);
-    if (f->owner) shm_unlink(f->name);
+    if (f->owner && !f->unlinked) shm_unlink(f->name);
     delete f;
     return VRC_OK;
 }

@@ -123,6 +123,11 @@ class PeerFrames:
                 capi.check(L.vrc_ipc_open_image(device, C.byref(buf), C.byref(tgt)))
                 self.targets.append(tgt)
                 r.setImageTarget(tgt)
+        # every rank has the segment mapped now: its name can go (the mappings stay valid), so that a run that is killed
+        # later -- launch_ranks ends stragglers by SIGKILL -- leaves nothing behind in /dev/shm
+        dist.barrier(group=group)
+        if rank == 0:
+            capi.check(L.vrc_ipc_flags_unlink(self._flags))
 
     def _written(self, slot, k):
         return slot * self.world + k
@@ -154,8 +159,9 @@ class PeerFrames:
 
     def wait(self, streams, timeout_s=120.0):
         """Instead of synchronising `streams` (raw stream pointers): returns when everything enqueued on them has completed;
-        raises VrcError (VRC_ERR_PEER) when a peer process is gone or nothing completes for timeout_s -- every wait on the flags
-        is then released in every process, so nobody hangs; the frames in flight are lost."""
+        raises VrcError (VRC_ERR_PEER) when a peer process is gone or no flag of the segment has moved for timeout_s (an
+        inactivity limit: a long queue that keeps completing frames is never declared dead) -- every wait on the flags is then
+        released in every process, so nobody hangs; the frames in flight are lost."""
         import ctypes as C
         from . import capi
         pids = (C.c_int32 * len(self.pids))(*self.pids)

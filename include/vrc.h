@@ -276,14 +276,18 @@ int vrc_ipc_flag_set(vrc_ipc_flags *f, uint32_t index, uint32_t value);
 /* A stream-ordered wait (vrc_stream_wait_flag) HAS NO TIMEOUT: if the process that should write the flag died, the stream --
  * and every hipStreamSynchronize on it -- waits for ever.  So a host never synchronises such a stream blindly; it calls
  * vrc_ipc_stream_wait: polls `stream` until everything enqueued on it has completed (VRC_OK), or until one of the peers
- * `pids` (process ids on this node, n_pids of them; may be NULL) no longer exists, or `timeout_ms` have passed (0 = no
- * deadline: only the peers' disappearance ends the wait), or another process has already given up on this segment.  On those three it gives up for everyone: marks the segment and writes
+ * `pids` (process ids on this node, n_pids of them; may be NULL) no longer exists, or NO FLAG of the segment has changed for `timeout_ms` (an inactivity limit, not a deadline from the
+ * start of the call: a healthy exchange that is still draining a long queue keeps moving its flags; 0 = no limit: only the
+ * peers' disappearance ends the wait), or another process has already given up on this segment.  On those three it gives up for everyone: marks the segment and writes
  * 0xffffffff into every flag from the host, which releases every wait on them in every process, holds them there while the
  * stream drains (the flag writes still queued behind the waits would lower them again) and returns VRC_ERR_PEER; call it for
  * every stream of the process before leaving, so that no wait stays pending on the device (frames completed after that are not valid; vrc_stream_wait_flag / _write_flag on a marked segment
  * fail with VRC_ERR_PEER as well).  Start a fresh process to try again. */
 int vrc_ipc_stream_wait(vrc_ipc_flags *f, void *stream, const int32_t *pids, uint32_t n_pids, uint32_t timeout_ms);
-int vrc_ipc_flags_close(vrc_ipc_flags *f);                     /* the creator also removes the segment */
+/* The creator removes the segment's NAME once every process of the run has opened it (the caller's barrier says when): the
+ * mappings stay valid, and a run that is killed afterwards leaves nothing behind in /dev/shm. */
+int vrc_ipc_flags_unlink(vrc_ipc_flags *f);
+int vrc_ipc_flags_close(vrc_ipc_flags *f);                     /* the creator also removes the name, if it has not yet */
 int vrc_stream_write_flag(vrc_ipc_flags *f, uint32_t index, uint32_t value, void *stream);
 int vrc_stream_wait_flag(vrc_ipc_flags *f, uint32_t index, uint32_t value, void *stream);      /* until flag >= value */
 uint32_t vrc_ipc_flag_value(const vrc_ipc_flags *f, uint32_t index);                           /* host read */

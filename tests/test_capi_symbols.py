@@ -109,7 +109,7 @@ def test_argument_validation_needs_no_gpu(built):
     assert L.vrc_ipc_flags_open(b"/vrc_x", 0, 0, 1, C.byref(f)) == -1
     assert L.vrc_ipc_flags_open(None, 8, 0, 1, C.byref(f)) == -1
     assert L.vrc_stream_write_flag(None, 0, 1, None) == -1 and L.vrc_stream_wait_flag(None, 0, 1, None) == -1
-    assert L.vrc_ipc_flag_value(None, 0) == 0 and L.vrc_ipc_flags_close(None) == 0
+    assert L.vrc_ipc_flag_value(None, 0) == 0 and L.vrc_ipc_flags_close(None) == 0 and L.vrc_ipc_flags_unlink(None) == -1
     assert L.vrc_ipc_export_image(None, None) == -1 and L.vrc_ipc_open_image(0, None, None) == -1
     assert L.vrc_renderer_set_image_target(None, None) == -1
 

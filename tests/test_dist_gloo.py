@@ -70,11 +70,14 @@ def _worker(rank, world, port, W, H, q):
 
 @pytest.mark.parametrize("world,W,H", [(2, 200, 100),      # 13 row blocks: uneven split over 2 and over 3 ranks, last block partial
                                        (3, 200, 100),
+                                       (4, 48, 1080),      # ... on 4 ranks: 135 row blocks = 34 + 34 + 34 + 33 (33.75 each: the uneven case between 3 and 8)
                                        (8, 48, 1080)])     # BASELINE configs 3/4's height on 8 ranks: 135 row blocks = seven ranks own 17, rank 7 owns 16
 def test_sharded_frame_over_gloo_ranks_matches_unsharded(built, heights, textures, world, W, H):
     import oracle_lib as O
     import cpuvoxelraycaster_amd as vrc
     import cpuvoxelraycaster_amd.dist as vd
+    if world == 4:
+        assert [len(vd.owned_rows(H, vd.ROW_BLOCK, r, world)) // vd.ROW_BLOCK for r in range(4)] == [34, 34, 34, 33]
     if world == 8:
         assert [len(vd.owned_rows(H, vd.ROW_BLOCK, r, world)) // vd.ROW_BLOCK for r in range(8)] == [17] * 7 + [16]
     ctx = mp.get_context("spawn")

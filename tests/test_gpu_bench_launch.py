@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("world,gather", [(2, "root"), (8, "peer")])
+@pytest.mark.parametrize("world,gather", [(2, "root"), (4, "root"), (8, "peer")])
 def test_plain_bench_line_launches_its_ranks(built, world, gather):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env["VRC_DIST_BACKEND"] = "gloo"
@@ -23,8 +23,14 @@ def test_plain_bench_line_launches_its_ranks(built, world, gather):
     d = json.loads(out.stdout.strip().splitlines()[-1])
     assert d["n_gpus"] == world and d["config"]["ranks_in_process_group"] == world
     assert d["config"]["gathered_frame_equals_unsharded"] is True
+    # the line validates itself at N > 1 (round-4 verdict, Next 2): the GATHERED frame 0 and the ranks' summed counters against the oracle
+    assert d["config"]["frame_equals_oracle"] is True, d["config"].get("frame_equals_oracle_is")
+    assert f"{world} ranks" in d["config"]["frame_equals_oracle_is"]
+    assert len(d["config"]["per_rank"]) == world and [r["rank"] for r in d["config"]["per_rank"]] == list(range(world))
+    assert all(r["kernel_ms_render_only"] > 0 for r in d["config"]["per_rank"])
+    assert d["config"]["exchange"]["backend"] == "gloo" and "rehearsal" in d["config"]["sharding"].lower() or gather == "peer"
     assert d["config"]["launched_by"].startswith("bench.py itself") and d["config"]["distinct_gpus"] == 1
-    log = os.path.join(ROOT, "gpurun_out", "r04")
+    log = os.path.join(ROOT, "gpurun_out", "r05")
     os.makedirs(log, exist_ok=True)
     with open(os.path.join(log, f"self_launch_gloo{world}_{gather}.json.log"), "w") as f:
         f.write(json.dumps(d) + "\n")

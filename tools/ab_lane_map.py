@@ -1,5 +1,5 @@
-import sys, time, json
-sys.path.insert(0, "/root/repo")
+import os, sys, time, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np
 import cpuvoxelraycaster_amd as vrc
 cfgs = {"c3": (9, 1920, 1080, 4, 0.0), "c4": (9, 1920, 1080, 4, 0.5), "c5": (10, 3840, 2160, 16, 0.0)}
