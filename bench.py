@@ -67,7 +67,6 @@ CONFIGS = {
                label="1024^3 LSVO terrain, 3840x2160, 16 spp GI"),
 }
 ROW_BLOCK = 8
-HANDOVER_DEFAULT = 0     # vrc_renderer_set_handover for the timed renderers (0 = off)
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -452,9 +451,6 @@ def main():
     ap.add_argument("--lane-samples", type=int, default=0, choices=[0, 1, 4],
                     help="lane <-> (pixel, sample) map of the frame kernel (vrc_renderer_set_lane_samples): 1 = 8 x 8 pixels per wave, "
                          "4 = 4 x 4 pixels x 4 samples abreast, 0 = the library's choice")
-    ap.add_argument("--handover", type=int, default=-1,
-                    help="hand-over of the GI stages' stragglers inside a workgroup (vrc_renderer_set_handover): lanes still walking at which a "
-                         "wave hands over, 1..16; 0 = off; -1 = the default of this bench (see HANDOVER_DEFAULT)")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra measurements (2-bounce extension)")
     ap.add_argument("--tuning", default="", help="blocks_per_cu: workgroups of the frame kernel per CU (= which waves-per-SIMD build), 0 = the library's choice")
     args = ap.parse_args()
@@ -540,8 +536,6 @@ def main():
     whole_spp_units = F > 1 if args.whole_spp == "auto" else args.whole_spp == "1"
     fused = whole_spp_units if args.fused == "auto" else args.fused == "1"
 
-    handover = HANDOVER_DEFAULT if args.handover < 0 else args.handover
-
     def make_renderer(whole=None):
         r = vrc.RayCaster(svo, (W, H))
         r.setLightPosition(light)
@@ -551,8 +545,6 @@ def main():
             r.setSampleChunk(spp)
         if args.lane_samples:
             r.setLaneSamples(args.lane_samples)
-        if handover:
-            r.setHandover(handover)
         return r
 
     rcs = [make_renderer() for _ in range(F)]
@@ -1156,7 +1148,6 @@ def main():
                        "ms_per_step_is": (f"frame PERIOD with {F} frames in flight (all `steps` frames complete inside the timed region); the LATENCY of one "
                                           "frame, rendered alone, is extra.one_frame_in_flight.ms_per_step" if F > 1 else
                                           "frame latency = period: one frame at a time on one stream"),
-                       "handover_cut_lanes": handover,
                        "frames_in_flight": F, "whole_spp_work_units": whole_spp_units, "resolve_fused_into_frame_kernel": fused, "host_enqueue_us_per_step": round(host_enqueue_us, 1), "sharding": f"{ROW_BLOCK}-row blocks round-robin over {world} GPU(s)"
                        + ((", direct peer writes into rank 0's framebuffers (hipIpc), no collective" if args.gather == "peer" else
                           (f", RCCL {'gather to rank 0' if args.gather == 'root' else 'all-gather'} of RGBA8 shards" if backend == "nccl" else

@@ -59,7 +59,6 @@ struct Tuning {
     bool reuse_invariant = false;       // pinhole camera: walk a unit's sample-invariant rays once (never a process default)
     bool walk_from_root = false;        // measurement switch: no ray starts below the root
     uint32_t lane_samples = 0;          // lane <-> (pixel, sample) map of the stage-synchronous kernel: 0 = automatic, 1, 4
-    uint32_t handover_cut = 0;          // hand-over of the GI stages' stragglers inside a workgroup: 0 = off, else the lane count at which a wave hands over
 };
 Tuning g_tuning;
 std::mutex g_tuning_mu;
@@ -201,13 +200,6 @@ extern "C" int vrc_renderer_set_lane_samples(vrc_renderer* r, uint32_t samples)
     if (!r) return fail(VRC_ERR_INVALID, "null renderer");
     if (samples != 0 && samples != 1 && samples != 4) return fail(VRC_ERR_INVALID, "vrc_renderer_set_lane_samples: %u (0, 1 or 4)", samples);
     r->tuning.lane_samples = samples;
-    return VRC_OK;
-}
-extern "C" int vrc_renderer_set_handover(vrc_renderer* r, uint32_t cut_lanes)
-{
-    if (!r) return fail(VRC_ERR_INVALID, "null renderer");
-    if (cut_lanes > vrc::handover_max_cut() && cut_lanes != 255u) return fail(VRC_ERR_INVALID, "vrc_renderer_set_handover: %u lanes (0 = off, at most %u)", cut_lanes, vrc::handover_max_cut());
-    r->tuning.handover_cut = cut_lanes;
     return VRC_OK;
 }
 extern "C" const char* vrc_renderer_last_kernel(const vrc_renderer* r) { return r ? r->last_kernel : ""; }
@@ -703,22 +695,6 @@ int render_impl(vrc_renderer* r, const vrc_camera* cam, const vrc_frame_params* 
                                                "use fewer samples per call or a larger sample chunk", (unsigned long long)units);
         // one wave per unit until the chip is full: a shard of few tiles still spreads over all CUs
         want = (units + VRC_RENDER_BLOCK / 64 - 1) / (VRC_RENDER_BLOCK / 64);
-    }
-    // Hand-over of the GI stages' stragglers (vrc_renderer_set_handover): the pinhole one-bounce kernel on the 8 x 8 map, sample
-    // mode with GI, and work units of a tile's WHOLE sample set -- the four waves of a workgroup run their stages in step, so
-    // every unit must have the same number of them.  Any other launch takes the plain kernel.
-    if (tuning.handover_cut && a.lane_samples == 1u && a.p.use_samples && a.p.use_gi && a.p.gi_bounces <= 1u && a.p.spp > 1 &&
-        a.sample_chunk == 0u && a.sample_chunk_tail == 0u && !a.checker_wide && !a.walk_from_root && vrc::camera_is_pinhole(a.cam)) {
-        const uint32_t lds = 2u * s->depth * 1024u + 1536u + 128u + 544u + 32u + vrc::handover_lds_bytes();
-        if (163840u / lds >= 1u) {
-            a.handover_cut = tuning.handover_cut;
-            const uint32_t fit = 163840u / lds;
-            const uint64_t cap_ho = (uint64_t)s->cu_count * (bpc < fit ? bpc : fit);
-            const uint32_t grid_ho = (uint32_t)(want < cap_ho ? want : cap_ho);
-            HIP_TRY(vrc::launch_render(a, grid_ho, st, &r->last_kernel));
-            if (queue_used >= 0) r->queue_zero[1 - queue_used] = true;
-            return VRC_OK;
-        }
     }
     const uint32_t grid = (uint32_t)(want < cap ? want : cap);
     HIP_TRY(vrc::launch_render(a, grid, st, &r->last_kernel));

@@ -71,9 +71,6 @@ struct FrameArgs {
     // which lane <-> (pixel, sample) map of the stage-synchronous kernel: 1 = 8 x 8 pixels, 4 = 4 x 4 pixels x 4 samples abreast
     // (render_sync_body's NS); n_items then counts 64 lanes per 4 x 4 tile
     uint32_t lane_samples;
-    // hand-over of the GI stages' stragglers inside a workgroup (vrc_renderer_set_handover; pinhole one-bounce kernel, whole-spp
-    // units): 0 = off, else a wave hands over when at most this many of its lanes are still walking (1 .. 16)
-    uint32_t handover_cut;
     uint32_t* tile_done;
     uint32_t* resolve_dst;
     vrc_camera cam;
@@ -87,8 +84,6 @@ hipError_t launch_cast_ray_chains(const void* nodes, int depth, uint64_t n, cons
 hipError_t launch_grid_cast(const uint8_t* cells, int X, int Y, int Z, uint64_t n, const float* org, const float* dir,
                             vrc_hit* out, hipStream_t st);
 uint32_t sync_max_blocks_per_cu();    // register-limited workgroups per CU of k_render_sync
-uint32_t handover_lds_bytes();        // LDS a workgroup of the hand-over kernels needs on top (the pool)
-uint32_t handover_max_cut();
 uint32_t sync_s4_waves(bool pinhole); // waves per SIMD the samples-abreast builds were compiled for
 // The stage-synchronous kernels are built for 6 waves per SIMD (80 VGPRs), the lens one-bounce kernel also for 7 (72).
 // Rounds 2 and 3 shipped 7- and 8-wave builds of the pinhole kernels too, picked by a table (profiles/r03/sweep_waves.txt:

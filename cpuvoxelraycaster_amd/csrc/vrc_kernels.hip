@@ -432,170 +432,6 @@ __device__ __forceinline__ float gi_two_levels(const uint2* __restrict__ nodes, 
     return smax(0.0f, acc0 / 1.0f);
 }
 
-// ---- Hand-over of a stage's stragglers inside a workgroup (round 5; tests/tools/handover_study.py has the offline bound) -----
-// The GI and GI-shadow stages run at 0.44 / 0.52 of their lanes: a wave-stage lasts as long as its longest ray.  With
-// hand-over the four waves of a workgroup take their work units in step and run every GI stage together: a wave leaves the
-// walk loop as soon as at most `cut` of its lanes are still walking (ray_walk<.., CUT>), writes those rays' loop-top state
-// into a pool in LDS (64 bytes each, at most 4 x 16 = 64 rays), and ONE wave of the four -- they take turns -- walks the
-// pooled rays to their ends, compacted into its 64 lanes (ray_walk<.., RESUME>), on the stack columns of the lanes that own
-// them (all four waves' stacks are this workgroup's LDS: the owner finds its stack as its own walk would have left it, and
-// the GI shadow ray can start on it in place).  The owners then read the final state back and every transition (ray_finish,
-// the next ray's set-up, shading) runs at full lane utilisation exactly as before.  A ray's walk does not depend on the lane
-// that runs it: results, ray and iteration counts are bit for bit those of the plain kernel.
-constexpr uint32_t VRC_HO_POOL = 64u;                        // rays a workgroup-stage can pool
-constexpr uint32_t VRC_HO_MAX_CUT = VRC_HO_POOL / (VRC_RENDER_BLOCK / 64u);
-constexpr uint32_t VRC_HO_LDS_BYTES = 4u * VRC_HO_POOL * 16u + 16u;
-struct HandoverCtx {
-    uint4* pool;              // LDS: four planes of VRC_HO_POOL x 16 bytes {pos, t_min | t_coef, parent | t_offset, t_max | packed, -, -, -}
-    uint32_t* count;          // LDS: rays pooled in the current stage
-    stack_t* stk_wg;          // column 0 of the secondary stack (lds_dyn + VRC_RENDER_BLOCK): + the owner's thread index = its column
-    uint32_t cut;             // a wave hands over when at most this many of its lanes are still walking (1 .. VRC_HO_MAX_CUT)
-    uint32_t turn;            // whose turn it is to collect: the same in all four waves, they call in step
-};
-
-// ctr[0] += wave_steps, ctr[1] += the lanes with `casts` set: book_walk for a call that ALL lanes of the wave make
-__device__ __forceinline__ void book_walk_of(unsigned long long* ctr, uint32_t wave_steps, bool casts)
-{
-    const unsigned long long m = __ballot(casts);
-    if ((threadIdx.x & 63u) == 0u) {
-        __hip_atomic_fetch_add(ctr + 0, (unsigned long long)wave_steps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        __hip_atomic_fetch_add(ctr + 1, (unsigned long long)__popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-    }
-}
-
-// One stage's walk with hand-over.  Called by every lane of every wave of the workgroup, in step (it contains barriers):
-// `casts` = this lane casts a ray in this stage (counted like the reference counts it), `active` = ray_setup accepted it.
-template <int LOD_MODE>
-__device__ __forceinline__ void walk_stage_handover(Ray& r, const bool casts, const bool active, const uint2* __restrict__ nodes, stack_t* stk,
-                                                    const int depth, const float coef, unsigned long long* ctr, HandoverCtx& hc)
-{
-    const uint32_t lane = threadIdx.x & 63u;
-    book_not_executed(ctr, active, r);
-    unsigned long long live_mask = 0ull;
-    const uint32_t steps = ray_walk<LOD_MODE, false, true, true, true, false>(r, active, nodes, stk, depth, coef, 0.0f, hc.cut, &live_mask);
-    book_walk_of(ctr, steps, casts);
-    // ---- park the rays that are still walking
-    const bool live = ((live_mask >> lane) & 1ull) != 0ull;
-    uint32_t base = 0u;
-    if (live_mask) {                                                     // (wave-uniform)
-        if (lane == 0u) base = atomicAdd(hc.count, (uint32_t)__popcll(live_mask));
-        base = __builtin_amdgcn_readfirstlane(base);
-    }
-    const uint32_t mine = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(live_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)live_mask, 0u));
-    if (live) {
-        hc.pool[mine] = make_uint4(f2u(r.px), f2u(r.py), f2u(r.pz), f2u(r.t_min));
-        hc.pool[VRC_HO_POOL + mine] = make_uint4(f2u(r.tcx), f2u(r.tcy), f2u(r.tcz), r.parent_id);
-        hc.pool[2u * VRC_HO_POOL + mine] = make_uint4(f2u(r.tox), f2u(r.toy), f2u(r.toz), f2u(r.t_max));
-        reinterpret_cast<uint32_t*>(hc.pool + 3u * VRC_HO_POOL + mine)[0] =
-            (uint32_t)r.scale | (r.child_offset << 5) | (r.normal << 8) | (r.mirror << 11) | (threadIdx.x << 16);
-    }
-    __syncthreads();
-    const uint32_t collector = hc.turn & (VRC_RENDER_BLOCK / 64u - 1u);
-    hc.turn += 1u;
-    if ((threadIdx.x >> 6) == collector) {
-        const uint32_t total = __builtin_amdgcn_readfirstlane(*hc.count);
-        if (total) {
-            const bool has = lane < total;
-            Ray q;
-            q.tcx = q.tcy = q.tcz = q.tox = q.toy = q.toz = 0.0f;
-            q.px = q.py = q.pz = 1.0f; q.t_min = 0.0f; q.t_max = 0.0f; q.h = 0.0f; q.scale_f = 0.5f;
-            q.parent_id = 0u; q.scale = SVO_MAX - 1; q.child_offset = 0u; q.mirror = 0u; q.normal = 0u; q.complexity = 0u;
-            q.kind = 0u; q.shift = 0u; q.nd = make_uint2(0u, 0u);
-            uint32_t owner = threadIdx.x;
-            if (has) {
-                const uint4 w0 = hc.pool[lane], w1 = hc.pool[VRC_HO_POOL + lane], w2 = hc.pool[2u * VRC_HO_POOL + lane];
-                const uint32_t pk = reinterpret_cast<const uint32_t*>(hc.pool + 3u * VRC_HO_POOL + lane)[0];
-                q.px = u2f(w0.x); q.py = u2f(w0.y); q.pz = u2f(w0.z); q.t_min = u2f(w0.w);
-                q.tcx = u2f(w1.x); q.tcy = u2f(w1.y); q.tcz = u2f(w1.z); q.parent_id = w1.w;
-                q.tox = u2f(w2.x); q.toy = u2f(w2.y); q.toz = u2f(w2.z); q.t_max = u2f(w2.w);
-                q.scale = (int)(pk & 31u); q.child_offset = (pk >> 5) & 7u; q.normal = (pk >> 8) & 7u; q.mirror = (pk >> 11) & 7u;
-                owner = (pk >> 16) & (VRC_RENDER_BLOCK - 1u);
-                q.scale_f = u2f(((uint32_t)q.scale + 104u) << 23);          // 2^(scale - 23), :133
-            }
-            const uint32_t more = ray_walk<LOD_MODE, false, false, true, false, true>(q, has, nodes, hc.stk_wg + owner, depth, coef, 0.0f);
-            if (lane == 0u) {
-                __hip_atomic_fetch_add(ctr + 0, (unsigned long long)more, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                *hc.count = 0u;
-            }
-            if (has) {
-                hc.pool[lane] = make_uint4(f2u(q.px), f2u(q.py), f2u(q.pz), f2u(q.t_min));
-                reinterpret_cast<uint32_t*>(hc.pool + 3u * VRC_HO_POOL + lane)[0] =
-                    (uint32_t)q.scale | (q.child_offset << 5) | (q.normal << 8) | (q.kind << 11);
-            }
-        }
-    }
-    __syncthreads();
-    if (live) {
-        const uint4 w0 = hc.pool[mine];
-        const uint32_t pk = reinterpret_cast<const uint32_t*>(hc.pool + 3u * VRC_HO_POOL + mine)[0];
-        r.px = u2f(w0.x); r.py = u2f(w0.y); r.pz = u2f(w0.z); r.t_min = u2f(w0.w);
-        r.scale = (int)(pk & 31u); r.child_offset = (pk >> 5) & 7u; r.normal = (pk >> 8) & 7u; r.kind = (pk >> 11) & 3u;
-        r.scale_f = u2f(((uint32_t)r.scale + 104u) << 23);
-        r.shift = r.child_offset ^ r.mirror;
-    }
-}
-
-// gi_chain<true> (one indirect bounce, raycaster.hpp:169-207) with both walks handed over.  Called by every lane; `want` = this
-// pixel-sample has a primary hit (the lanes that call gi_chain in the plain kernel).
-__device__ __forceinline__ float gi_chain_handover(const uint2* __restrict__ nodes, stack_t* const stk_hit, const uint32_t base_scale,
-                                                   const uint2 root, const int depth,
-                                                   const float n_normalizer, const float lx, const float ly, const float lz,
-                                                   const uint32_t seed, const uint32_t fr, const uint32_t pix,
-                                                   const float base_px, const float base_py, const float base_pz,
-                                                   const float base_nx, const float base_ny, const float base_nz,
-                                                   const bool want, unsigned long long* ctr, HandoverCtx& hc)
-{
-    stack_t* const stk = stk_hit + VRC_RENDER_BLOCK;
-    Ray r;
-    r.tcx = r.tcy = r.tcz = r.tox = r.toy = r.toz = 0.0f;
-    r.px = r.py = r.pz = 1.0f; r.t_min = 0.0f; r.t_max = 0.0f; r.h = 0.0f; r.scale_f = 0.5f;
-    r.parent_id = 0u; r.scale = SVO_MAX - 1; r.child_offset = 0u; r.mirror = 0u; r.normal = 0u; r.complexity = 0u;
-    r.kind = 0u; r.shift = 0u; r.nd = root;
-    bool active = false;
-    float ox = 0.0f, oy = 0.0f, oz = 0.0f, dx = 0.0f, dy = 0.0f, dz = 0.0f, dot_gi = 0.0f;
-    if (want) {
-        ox = base_px + base_nx * n_normalizer;                           // :174
-        oy = base_py + base_ny * n_normalizer;
-        oz = base_pz + base_nz * n_normalizer;
-        const float c1 = get_rand(counter_rand(seed, fr, pix, 2u), -1000.0f, 1000.0f);
-        const float c2 = get_rand(counter_rand(seed, fr, pix, 3u), -1000.0f, 1000.0f);
-        float qx = 0.0f, qy = 0.0f, qz = 0.0f;
-        if (base_nx != 0.0f)      { qy = c1; qz = c2; }
-        else if (base_ny != 0.0f) { qx = c1; qz = c2; }
-        else if (base_nz != 0.0f) { qx = c1; qy = c2; }
-        dx = (base_nx + qx) * n_normalizer;                              // :192
-        dy = (base_ny + qy) * n_normalizer;
-        dz = (base_nz + qz) * n_normalizer;
-        normalize3(dx, dy, dz);
-        dot_gi = dot3(dx, dy, dz, base_nx, base_ny, base_nz);            // :193
-        active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
-        copy_stack<VRC_SYNC_ROW>(stk, stk_hit, depth);
-        ray_start_below(r, start_scale_next_to_lod(ox, oy, oz, base_px, base_py, base_pz, base_scale, dx, dy, dz), ox, oy, oz);
-    }
-    walk_stage_handover<1>(r, want, active, nodes, stk, depth, 0.5f, ctr, hc);        // :194
-    Hit g;
-    g.hit = 0u; g.px = g.py = g.pz = 0.0f; g.nx = g.ny = g.nz = 0.0f;
-    if (want) ray_finish(r, depth, ox, oy, oz, dx, dy, dz, g);
-    const bool sh = want && g.hit != 0u;                                 // :195-203
-    float contrib = 0.0f;
-    active = false;
-    if (sh) {
-        ox = g.px + g.nx * n_normalizer;
-        oy = g.py + g.ny * n_normalizer;
-        oz = g.pz + g.nz * n_normalizer;
-        dx = lx - ox; dy = ly - oy; dz = lz - oz;
-        normalize3(dx, dy, dz);
-        const float dotl = dot3(g.nx, g.ny, g.nz, dx, dy, dz);             // :200
-        contrib = 1000000.0f * smin(0.5f, smax(0.0f, dotl) * dot_gi);      // :201
-        active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
-        ray_start_below(r, start_scale_next_to_lod(ox, oy, oz, g.px, g.py, g.pz, (g.hit >> 16) & 0xffu, dx, dy, dz), ox, oy, oz);
-    }
-    walk_stage_handover<1>(r, sh, active, nodes, stk, depth, 0.5f, ctr, hc);          // :198
-    float acc = 0.0f;
-    if (sh && !r.kind) acc += contrib;
-    return smax(0.0f, acc / 1.0f);                                        // :206
-}
-
 // sink of one pixel-sample, raycaster.hpp:77-91: sum in registers (sample mode; one accumulator update per unit) or
 // the 0.4 / 0.6 temporal blend into render_image
 __device__ __forceinline__ void sink_sample(const FrameArgs& a, const uint32_t pix, const uint32_t color,
@@ -633,12 +469,9 @@ __device__ __forceinline__ uint32_t albedo_of(const uint8_t* tex, const Hit& h)
 // the longest of 16 neighbouring pixels' instead of 64 and a round issues fewer of the loop's blocks -- 6-11 % fewer VALU
 // instructions in the walks of the C3 frame, 4 % with a lens (tests/tools/tile_shape.py -> profiles/r04/tile_shape.json).
 // Every ray the reference casts is still walked and counted, each by its own lane.
-// HANDOVER (pinhole, one bounce, 8 x 8 map, whole-spp units): the GI stages hand their stragglers over inside the workgroup
-// (walk_stage_handover above); the four waves then take their work units in step.
-template <bool PINHOLE, bool ONE_BOUNCE, bool FUSED, bool FROM_ROOT = false, uint32_t NS = 1u, bool HANDOVER = false>
+template <bool PINHOLE, bool ONE_BOUNCE, bool FUSED, bool FROM_ROOT = false, uint32_t NS = 1u>
 __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
 {
-    static_assert(!HANDOVER || (PINHOLE && ONE_BOUNCE && !FROM_ROOT && NS == 1u), "hand-over exists for the pinhole one-bounce kernel");
     // [depth][2][256] two stacks, their rows interleaved | 1536 B textures | 4 waves x 4 counters | camera paths (8 x 16 entries + 8) |
     // 4 waves' count of iterations not executed
     extern __shared__ stack_t lds_dyn[];
@@ -663,17 +496,6 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
         const float isz = 1.0f / (float)(1u << a.depth);
         cam_path[threadIdx.x * 16u + 15u] = camera_path(nodes, depth, (a.cam.position[0] + 0.0f) * isz + 1.0f, (a.cam.position[1] + 0.0f) * isz + 1.0f,
                                                         (a.cam.position[2] + 0.0f) * isz + 1.0f, PINHOLE, threadIdx.x, cam_path + threadIdx.x * 16u);
-    }
-    // hand-over: the pool and its count behind everything else (launch_render adds VRC_HO_LDS_BYTES)
-    HandoverCtx hc;
-    if constexpr (HANDOVER) {
-        uint8_t* const ho = tex + 1536 + 128 + VRC_CAMERA_PATH_BYTES + 32;
-        hc.pool = reinterpret_cast<uint4*>(ho);
-        hc.count = reinterpret_cast<uint32_t*>(ho + 4u * VRC_HO_POOL * 16u);
-        hc.stk_wg = lds_dyn + VRC_RENDER_BLOCK;
-        hc.cut = a.handover_cut == 255u ? 0u : min(max(a.handover_cut, 1u), VRC_HO_MAX_CUT);   // (255: experiment -- the lockstep and its barriers without any hand-over)
-        hc.turn = blockIdx.x;
-        if (threadIdx.x == 0u) *hc.count = 0u;
     }
     __syncthreads();
     if (threadIdx.x == 0u) {
@@ -740,27 +562,18 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
 #endif
 
     for (;;) {
-        uint32_t unit = n_units;
-        while (heads_tried < 8u) {
-            uint32_t got = 0u;
-            if (lane == 0u) {
-                // after the first dry head, look before taking: a dry head then costs a load, not an atomic
-                uint32_t* q = a.queue + head * VRC_QUEUE_STRIDE;
-                got = heads_tried ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-                if (got * 8u + head < n_units) got = atomicAdd(q, 1u);
-            }
-            unit = __builtin_amdgcn_readfirstlane(got) * 8u + head;
-            if (unit < n_units) break;
-            ++heads_tried;
-            head = (head + 1u) & 7u;
+        uint32_t unit = 0u;
+        if (lane == 0u) {
+            // after the first dry head, look before taking: a dry head then costs a load, not an atomic
+            uint32_t* q = a.queue + head * VRC_QUEUE_STRIDE;
+            unit = heads_tried ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            if (unit * 8u + head < n_units) unit = atomicAdd(q, 1u);
         }
-        const bool have_unit = unit < n_units;
-        if constexpr (HANDOVER) {
-            // the four waves go on in step until none of them finds a unit: a wave without one still takes part in the stages'
-            // barriers (and its turns at collecting), with no pixel of its own
-            if (!__syncthreads_or(have_unit ? 1 : 0)) break;
-        } else {
-            if (!have_unit) break;
+        unit = __builtin_amdgcn_readfirstlane(unit) * 8u + head;
+        if (unit >= n_units) {
+            if (++heads_tried == 8u) break;
+            head = (head + 1u) & 7u;
+            continue;
         }
 #ifdef VRC_PROBE
         ++probe_units;
@@ -795,7 +608,7 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
             const uint32_t ah = H / 4u, y0 = ah ? (px_y / ah) * ah : 0u;
             px_x = tx * 16u + 2u * (lane & 7u) + ((px_y - y0 + (uint32_t)a.p.checker_parity) & 1u);
         }
-        const bool valid = have_unit && px_x < W && px_y < H && pixel_selected(a.p, W, H, px_x, px_y);
+        const bool valid = px_x < W && px_y < H && pixel_selected(a.p, W, H, px_x, px_y);
         const uint32_t pix = px_y * W + px_x;
         uint32_t acc_r = 0u, acc_g = 0u, acc_b = 0u;
 
@@ -876,20 +689,6 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
                 }
             }
             // ---- per sample: the GI pair (raycaster.hpp:161,169-207), shading, sink
-            if constexpr (HANDOVER) {
-                // (whole-spp units only: every wave of the workgroup runs the same number of stages; the host guarantees it)
-                for (uint32_t sample = 0u; sample < spp; ++sample) {
-                    float gi_intensity = 0.0f;
-                    if (a.p.use_gi)
-                        gi_intensity = gi_chain_handover(nodes, stk, albedo >> 24, root, depth, n_normalizer, lx, ly, lz, a.p.seed,
-                                                         a.p.frame_index + sample, pix, hpx, hpy, hpz, hnx, hny, hnz, valid && hit, ctr, hc);
-                    if (valid) {
-                        uint32_t color = 0u;                                         // ColorResult: Black
-                        if (hit) color = color_mult(albedo, smin(1.0f, smax(0.0f, light_intensity + gi_intensity)));   // :163
-                        sink_sample(a, pix, color, acc_r, acc_g, acc_b);
-                    }
-                }
-            } else
             for (uint32_t sample = s_begin; sample < s_end; ++sample) {
                 if (valid) {
                     uint32_t color = 0u;                                             // ColorResult: Black
@@ -1150,21 +949,6 @@ VRC_SYNC_KERNEL_NS(k_render_sync_s4, false, true, false, VRC_SYNC_S4_WAVES_LENS,
 VRC_SYNC_KERNEL_NS(k_render_sync_resolved_s4, false, true, true, VRC_SYNC_S4_WAVES_LENS, 4u)
 VRC_SYNC_KERNEL_NS(k_render_sync_pinhole_s4, true, true, false, VRC_SYNC_S4_WAVES, 4u)
 VRC_SYNC_KERNEL_NS(k_render_sync_pinhole_resolved_s4, true, true, true, VRC_SYNC_S4_WAVES, 4u)
-// the pinhole one-bounce kernel with hand-over of the GI stages' stragglers (render_sync_body's HANDOVER): whole-spp units only
-#if !(defined(VRC_WALK_CPP) || defined(VRC_PROBE) || defined(VRC_NO_START_BELOW))
-#define VRC_HAVE_HANDOVER 1
-#ifndef VRC_SYNC_HO_WAVES
-#define VRC_SYNC_HO_WAVES 6
-#endif
-#define VRC_SYNC_KERNEL_HO(name, FUSED)                                                                    \
-    extern "C" __global__ void __launch_bounds__(VRC_RENDER_BLOCK, VRC_SYNC_HO_WAVES) name(const FrameArgs a)  \
-    {                                                                                                      \
-        render_sync_body<true, true, FUSED, false, 1u, true>(a);                                           \
-    }
-VRC_SYNC_KERNEL_HO(k_render_sync_pinhole_ho, false)
-VRC_SYNC_KERNEL_HO(k_render_sync_pinhole_resolved_ho, true)
-#undef VRC_SYNC_KERNEL_HO
-#endif
 #undef VRC_SYNC_KERNEL
 #undef VRC_SYNC_KERNEL_NS
 // every kernel of the 8 x 8 map once more with every ray started at the root, as lsvo.hpp:60-72 does
@@ -1373,8 +1157,6 @@ hipError_t launch_grid_cast(const uint8_t* cells, int X, int Y, int Z, uint64_t 
 }
 
 uint32_t sync_max_blocks_per_cu() { return VRC_SYNC_MIN_WAVES; }
-uint32_t handover_lds_bytes() { return VRC_HO_LDS_BYTES; }
-uint32_t handover_max_cut() { return VRC_HO_MAX_CUT; }
 uint32_t sync_s4_waves(bool pinhole) { return pinhole ? VRC_SYNC_S4_WAVES : VRC_SYNC_S4_WAVES_LENS; }
 uint32_t sync_waves_for(bool pinhole, bool one_bounce, bool use_gi, bool whole_spp_units, uint64_t pixel_samples, uint32_t requested)
 {
@@ -1405,23 +1187,14 @@ hipError_t launch_render(const FrameArgs& a, uint32_t grid_blocks, hipStream_t s
 {
     const char* name = "";
     {
-        size_t lds = 2 * (size_t)a.depth * VRC_RENDER_BLOCK * sizeof(stack_t) + 1536 + 128 + VRC_CAMERA_PATH_BYTES + 32;   // two stacks, tables, the waves' counters, camera paths, iterations not executed
+        const size_t lds = 2 * (size_t)a.depth * VRC_RENDER_BLOCK * sizeof(stack_t) + 1536 + 128 + VRC_CAMERA_PATH_BYTES + 32;   // two stacks, tables, the waves' counters, camera paths, iterations not executed
         const bool pinhole = camera_is_pinhole(a.cam);
         const bool one = a.p.gi_bounces <= 1u, fused = a.fused_resolve != 0u;
         const uint32_t waves = a.waves;
         struct Build { void (*fn)(const FrameArgs); const char* name; };
 #define VRC_BUILD(k) Build{k, #k}
         const bool s4 = a.lane_samples == 4u && one;
-#ifdef VRC_HAVE_HANDOVER
-        const bool ho = a.handover_cut != 0u && pinhole && one && !s4 && !a.walk_from_root;
-        if (ho) lds += VRC_HO_LDS_BYTES;
-#else
-        const bool ho = false;
-#endif
         const Build b =
-#ifdef VRC_HAVE_HANDOVER
-            ho ? (fused ? VRC_BUILD(k_render_sync_pinhole_resolved_ho) : VRC_BUILD(k_render_sync_pinhole_ho)) :
-#endif
             s4 ? (pinhole ? (fused ? VRC_BUILD(k_render_sync_pinhole_resolved_s4) : VRC_BUILD(k_render_sync_pinhole_s4))
                           : (fused ? VRC_BUILD(k_render_sync_resolved_s4) : VRC_BUILD(k_render_sync_s4))) :
             a.walk_from_root ? (pinhole ? (one ? (fused ? VRC_BUILD(k_render_sync_pinhole_resolved_from_root) : VRC_BUILD(k_render_sync_pinhole_from_root))

@@ -60,15 +60,6 @@ __device__ __forceinline__ walk_rsrc_t walk_node_rsrc(const uint2* __restrict__ 
 #define VRC_WALK_COUNT_WAVE                                                                     \
     "s_bcnt1_i32_b64 %[sb], exec\n"                                                             \
     "s_add_u32 %[ssteps], %[ssteps], %[sb]\n"
-// ... for a walk that may be CUT (hand-over, vrc_kernels.hip: gi_stage_handover): when at most %[scut] lanes are still walking
-// the loop is left at this loop top, BEFORE the iteration is counted or executed -- the lanes in %[srun] keep the complete
-// loop-top state of their rays (pos, t_min, parent, child, the row of their scale), and whoever resumes them (RESUME below)
-// counts and executes this iteration.
-#define VRC_WALK_COUNT_WAVE_CUT                                                                 \
-    "s_bcnt1_i32_b64 %[sb], exec\n"                                                             \
-    "s_cmp_le_u32 %[sb], %[scut]\n"                                                             \
-    "s_cbranch_scc1 Lwalk_done%=\n"                                                             \
-    "s_add_u32 %[ssteps], %[ssteps], %[sb]\n"
 
 // The tests of :81-89 that leave EXEC = the lanes whose child exists and whose span is not empty (LOD cuts taken out).
 // Without a LOD test: t_min <= min(t_max, tc) in one min and one compare (:81 is implied, see ray_step).
@@ -103,23 +94,13 @@ __device__ __forceinline__ walk_rsrc_t walk_node_rsrc(const uint2* __restrict__ 
 // scale in %[t] and the (mirrored) ray origin in px, py, pz -- stack row -> parent, scale_f, pos = the origin's bits above the
 // scale, child bits, node load: exactly the state a pop to that scale leaves (:133-143).  The other lanes start at the root.
 #define VRC_WALK_START_ROOT ""
-// RESUME: the lanes arrive with the loop-top state a cut walk left (possibly another wave's); only the node is fetched again
-#define VRC_WALK_START_RESUME VRC_WALK_LOAD_NODE
 #define VRC_WALK_START_BELOW                                                                    \
     "v_cmpx_gt_u32_e32 vcc, 22, %[t]\n"                                                         \
     "s_cbranch_execnz Lwalk_start%=\n"                                                          \
     "s_mov_b64 exec, %[srun]\n"
 
 // v46:47 node
-#define VRC_WALK_CAP_PLAIN "s_cbranch_scc1 Lwalk_done%=\n"
-#define VRC_WALK_CAP_CUT "s_cbranch_scc1 Lwalk_cap%=\n"      /* a cut walk reports the lanes still walking in srun: the cap clears it */
-#define VRC_WALK_TAIL_PLAIN ""
-#define VRC_WALK_TAIL_CUT                                                                       \
-    "s_branch Lwalk_done%=\n"                                                                   \
-    "Lwalk_cap%=:\n"                                                                            \
-    "s_mov_b64 %[srun], 0\n"
-#define VRC_WALK_ASM(SPANPART, COUNTPART, STARTPART, ROWSH, ROWDOWN) VRC_WALK_ASM_X(SPANPART, COUNTPART, STARTPART, ROWSH, ROWDOWN, VRC_WALK_CAP_PLAIN, VRC_WALK_TAIL_PLAIN)
-#define VRC_WALK_ASM_X(SPANPART, COUNTPART, STARTPART, ROWSH, ROWDOWN, CAPPART, TAILPART)                      \
+#define VRC_WALK_ASM(SPANPART, COUNTPART, STARTPART, ROWSH, ROWDOWN)                                           \
     "s_mov_b64 %[sentry], exec\n"                                                               \
     "s_and_b64 exec, exec, %[sx]\n"             /* the lanes with a ray to walk (%[sx] arrives holding them) */ \
     "s_mov_b64 %[sleaf], 0\n"                                                                   \
@@ -130,7 +111,7 @@ __device__ __forceinline__ walk_rsrc_t walk_node_rsrc(const uint2* __restrict__ 
     STARTPART                                                                                   \
     "Lwalk_loop%=:\n"                                                                           \
     "s_add_u32 %[siter], %[siter], 1\n"                                                         \
-    CAPPART                                     /* safety net */                                \
+    "s_cbranch_scc1 Lwalk_done%=\n"             /* safety net */                                \
     COUNTPART                                   /* :73 ++complexity */                          \
     "v_xor_b32_e32 %[kind], %[co], %[mirror]\n"   /* :79 child_shift */                           \
     "v_mul_f32_e32 %[cx], %[px], %[tcx]\n"      /* :76 */                                       \
@@ -237,7 +218,6 @@ __device__ __forceinline__ walk_rsrc_t walk_node_rsrc(const uint2* __restrict__ 
     "Lwalk_next%=:\n"                                                                           \
     "s_mov_b64 exec, %[srun]\n"                                                                 \
     "s_cbranch_execnz Lwalk_loop%=\n"                                                           \
-    TAILPART                                                                                    \
     "Lwalk_done%=:\n"                                                                           \
     "s_waitcnt vmcnt(0) lgkmcnt(0)\n"                                                           \
     "s_or_b64 exec, %[sleaf], %[slod]\n"                                                        \
@@ -257,20 +237,13 @@ __device__ __forceinline__ walk_rsrc_t walk_node_rsrc(const uint2* __restrict__ 
 // start at that scale instead of at the root -- see start_scale_next_to for when that is the walk the reference does; the
 // iterations such a lane does not execute (22 - scale) are NOT in the return value, the caller books them (COUNT_LANE: the
 // caller presets r.complexity with them).
-// CUT (frame kernels with hand-over, COUNT_LANE = false, TWO_STACKS): the loop is left as soon as at most `cut_lanes` lanes are
-// still walking; *live_out = those lanes (0 when every ray has ended), whose Ray holds the loop-top state to resume from.
-// RESUME: the lanes with `active` set arrive with such a state (r.scale = the level, r.parent_id, r.child_offset, r.normal, pos,
-// t_min, scale_f and the ray's constants) and `stk` = the column of the stack the cut walk used.
-template <int LOD_MODE, bool COUNT_LANE, bool BELOW = false, bool TWO_STACKS = false, bool CUT = false, bool RESUME = false>
+template <int LOD_MODE, bool COUNT_LANE, bool BELOW = false, bool TWO_STACKS = false>
 __device__ __forceinline__ uint32_t ray_walk(Ray& r, bool active, const uint2* __restrict__ nodes, stack_t* stk,
-                                             int depth, float coef, float bias, uint32_t cut_lanes = 0u, unsigned long long* live_out = nullptr)
+                                             int depth, float coef, float bias)
 {
-    static_assert(!(CUT && COUNT_LANE) && !(CUT && RESUME) && !(RESUME && BELOW), "cut walks count per wave; a resumed walk runs to its end");
-    static_assert(!(CUT || RESUME) || TWO_STACKS, "hand-over exists in the frame kernels only");
     // (no branch around the loop for the lanes without a ray: the loop masks them itself, so that the SGPR results
     // are the same for every lane that made the call)
     const unsigned long long sact = __ballot(active);
-    const uint32_t scut = CUT ? __builtin_amdgcn_readfirstlane(cut_lanes) : 0u;     // wave-uniform, in an SGPR
     // LDS byte address of slot 0 minus the rows of the scales that have no slot (slot = scale - depth_off)
     const uint32_t stkb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) stack_t*)stk
                           - (uint32_t)(SVO_MAX - depth) * (TWO_STACKS ? 2048u : 1024u);
@@ -293,39 +266,27 @@ __device__ __forceinline__ uint32_t ray_walk(Ray& r, bool active, const uint2* _
           [siter] "=&s"(siter), [m] "=&v"(m), [t] "+&v"(t), [t2] "=&v"(t2), [tc] "=&v"(tc),                           \
           [cx] "=&v"(cx), [cy] "=&v"(cy), [cz] "=&v"(cz)                                                              \
         : [tcx] "v"(r.tcx), [tcy] "v"(r.tcy), [tcz] "v"(r.tcz), [tox] "v"(r.tox), [toy] "v"(r.toy), [toz] "v"(r.toz), \
-          [mirror] "v"(r.mirror), [stkb] "v"(stkb), VRC_WALK_NODES_OPERAND [sfc] "s"(sfc), [coef] "v"(coef), [bias] "v"(bias), [tmax] "v"(r.t_max), \
-          [scut] "s"(scut)                                                                                       \
+          [mirror] "v"(r.mirror), [stkb] "v"(stkb), VRC_WALK_NODES_OPERAND [sfc] "s"(sfc), [coef] "v"(coef), [bias] "v"(bias), [tmax] "v"(r.t_max) \
         : "vcc", "scc", "memory"
 #define VRC_WALK_OPS_LANE [cmpl] "+&v"(cmpl)
 #define VRC_WALK_OPS_WAVE [ssteps] "+&s"(ssteps), [sb] "=&s"(sb)
-#define VRC_WALK_RUN_PLAIN(SPAN, COUNT, OPS)                                                                        \
+#define VRC_WALK_RUN(SPAN, COUNT, OPS)                                                                              \
     do {                                                                                                            \
         if (BELOW && TWO_STACKS) asm volatile(VRC_WALK_ASM(SPAN, COUNT, VRC_WALK_START_BELOW, "11", "0xfffff800") VRC_WALK_OPERANDS(OPS)); \
         else if (TWO_STACKS) asm volatile(VRC_WALK_ASM(SPAN, COUNT, VRC_WALK_START_ROOT, "11", "0xfffff800") VRC_WALK_OPERANDS(OPS)); \
         else if (BELOW) asm volatile(VRC_WALK_ASM(SPAN, COUNT, VRC_WALK_START_BELOW, "10", "0xfffffc00") VRC_WALK_OPERANDS(OPS));      \
         else asm volatile(VRC_WALK_ASM(SPAN, COUNT, VRC_WALK_START_ROOT, "10", "0xfffffc00") VRC_WALK_OPERANDS(OPS));                  \
     } while (0)
-#define VRC_WALK_RUN(SPAN, COUNT, OPS)                                                                              \
-    do {                                                                                                            \
-        if (CUT && BELOW) asm volatile(VRC_WALK_ASM_X(SPAN, VRC_WALK_COUNT_WAVE_CUT, VRC_WALK_START_BELOW, "11", "0xfffff800", VRC_WALK_CAP_CUT, VRC_WALK_TAIL_CUT) VRC_WALK_OPERANDS(OPS)); \
-        else if (CUT) asm volatile(VRC_WALK_ASM_X(SPAN, VRC_WALK_COUNT_WAVE_CUT, VRC_WALK_START_ROOT, "11", "0xfffff800", VRC_WALK_CAP_CUT, VRC_WALK_TAIL_CUT) VRC_WALK_OPERANDS(OPS)); \
-        else if (RESUME) asm volatile(VRC_WALK_ASM(SPAN, COUNT, VRC_WALK_START_RESUME, "11", "0xfffff800") VRC_WALK_OPERANDS(OPS)); \
-        else if (BELOW && TWO_STACKS) asm volatile(VRC_WALK_ASM(SPAN, COUNT, VRC_WALK_START_BELOW, "11", "0xfffff800") VRC_WALK_OPERANDS(OPS)); \
-        else if (TWO_STACKS) asm volatile(VRC_WALK_ASM(SPAN, COUNT, VRC_WALK_START_ROOT, "11", "0xfffff800") VRC_WALK_OPERANDS(OPS)); \
-        else if (BELOW) asm volatile(VRC_WALK_ASM(SPAN, COUNT, VRC_WALK_START_BELOW, "10", "0xfffffc00") VRC_WALK_OPERANDS(OPS));      \
-        else asm volatile(VRC_WALK_ASM(SPAN, COUNT, VRC_WALK_START_ROOT, "10", "0xfffffc00") VRC_WALK_OPERANDS(OPS));                  \
-    } while (0)
     if (COUNT_LANE) {
-        if (LOD_MODE == 0) VRC_WALK_RUN_PLAIN(VRC_WALK_SPAN_NOLOD, VRC_WALK_COUNT_LANE, VRC_WALK_OPS_LANE);
-        else if (LOD_MODE == 1) VRC_WALK_RUN_PLAIN(VRC_WALK_SPAN_LOD(VRC_WALK_BIAS_NONE), VRC_WALK_COUNT_LANE, VRC_WALK_OPS_LANE);
-        else VRC_WALK_RUN_PLAIN(VRC_WALK_SPAN_LOD(VRC_WALK_BIAS_ADD), VRC_WALK_COUNT_LANE, VRC_WALK_OPS_LANE);
+        if (LOD_MODE == 0) VRC_WALK_RUN(VRC_WALK_SPAN_NOLOD, VRC_WALK_COUNT_LANE, VRC_WALK_OPS_LANE);
+        else if (LOD_MODE == 1) VRC_WALK_RUN(VRC_WALK_SPAN_LOD(VRC_WALK_BIAS_NONE), VRC_WALK_COUNT_LANE, VRC_WALK_OPS_LANE);
+        else VRC_WALK_RUN(VRC_WALK_SPAN_LOD(VRC_WALK_BIAS_ADD), VRC_WALK_COUNT_LANE, VRC_WALK_OPS_LANE);
     } else {
         if (LOD_MODE == 0) VRC_WALK_RUN(VRC_WALK_SPAN_NOLOD, VRC_WALK_COUNT_WAVE, VRC_WALK_OPS_WAVE);
         else if (LOD_MODE == 1) VRC_WALK_RUN(VRC_WALK_SPAN_LOD(VRC_WALK_BIAS_NONE), VRC_WALK_COUNT_WAVE, VRC_WALK_OPS_WAVE);
         else VRC_WALK_RUN(VRC_WALK_SPAN_LOD(VRC_WALK_BIAS_ADD), VRC_WALK_COUNT_WAVE, VRC_WALK_OPS_WAVE);
     }
 #undef VRC_WALK_RUN
-#undef VRC_WALK_RUN_PLAIN
 #undef VRC_WALK_OPS_LANE
 #undef VRC_WALK_OPS_WAVE
 #undef VRC_WALK_OPERANDS
@@ -335,7 +296,6 @@ __device__ __forceinline__ uint32_t ray_walk(Ray& r, bool active, const uint2* _
     if (COUNT_LANE) r.complexity = cmpl;
     r.kind = kind;                              // 0 for a lane without a ray, as ray_setup left it
     r.shift = co ^ r.mirror;                    // child_shift of the child that was hit (unused on a miss)
-    if (CUT) *live_out = srun;
     return ssteps;
 }
 

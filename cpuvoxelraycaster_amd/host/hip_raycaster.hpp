@@ -246,7 +246,6 @@ public:
     // ... and, beyond the reference, the sample-invariant primary / shadow walks of a pinhole camera done once per unit
     void setInvariantRayReuse(bool on) { check(vrc_renderer_set_invariant_ray_reuse(r_, on ? 1u : 0u), "vrc_renderer_set_invariant_ray_reuse"); }
     void setLaneSamples(uint32_t samples) { check(vrc_renderer_set_lane_samples(r_, samples), "vrc_renderer_set_lane_samples"); }
-    void setHandover(uint32_t cut_lanes) { check(vrc_renderer_set_handover(r_, cut_lanes), "vrc_renderer_set_handover"); }
     void setWalkFromRoot(bool on) { check(vrc_renderer_set_walk_from_root(r_, on ? 1u : 0u), "vrc_renderer_set_walk_from_root"); }
 
     void samples_to_image(void* stream = nullptr) { check(vrc_samples_to_image(r_, stream), "vrc_samples_to_image"); }   // raycaster.hpp:94

@@ -223,12 +223,6 @@ class RayCaster:
         0 = the library's choice.  Same results either way.  include/vrc.h: vrc_renderer_set_lane_samples."""
         check(capi.load().vrc_renderer_set_lane_samples(self._h, samples))
 
-    def setHandover(self, cut_lanes=16):
-        """the GI stages hand their stragglers over inside the workgroup once at most `cut_lanes` (1..16) of a wave's rays are
-        still walking; 0 = off.  Whole-spp work units only (setSampleChunk(spp)).  Same results.  include/vrc.h:
-        vrc_renderer_set_handover."""
-        check(capi.load().vrc_renderer_set_handover(self._h, cut_lanes))
-
     def setInvariantRayReuse(self, on=True):
         """beyond the reference: pinhole camera, walk a work unit's primary and shadow ray once instead of once per sample
         (same image; stats then count the walks executed).  include/vrc.h: vrc_renderer_set_invariant_ray_reuse."""

@@ -400,17 +400,6 @@ int vrc_renderer_set_walk_from_root(vrc_renderer *r, uint32_t on);
  * same either way. */
 int vrc_renderer_set_lane_samples(vrc_renderer *r, uint32_t samples);
 int vrc_set_lane_samples(uint32_t samples);                 /* the process default new renderers copy */
-/* Hand-over of the GI stages' stragglers inside a workgroup (round 5).  A stage of the frame kernel
- * lasts as long as its longest ray (the reference's workers have the same tail: a swarm area is
- * done when its slowest pixel is, main.cpp:139-154).  cut_lanes = 1..16: in the GI and GI-shadow
- * stages a wave leaves the walk as soon as at most cut_lanes of its 64 rays are still walking and
- * hands them to ONE wave of its workgroup, which walks the four waves' stragglers together; 0 =
- * off (default).  Applies to sample-mode frames with GI and one bounce from a pinhole camera whose
- * work units are a tile's whole sample set (vrc_renderer_set_sample_chunk(r, spp)) on the 8 x 8
- * lane map; every other launch runs the plain kernel (vrc_renderer_last_kernel ends in "_ho" when
- * it applied).  Image, accumulators and vrc_frame_stats are the same either way: a ray's walk does
- * not depend on the lane that runs it. */
-int vrc_renderer_set_handover(vrc_renderer *r, uint32_t cut_lanes);
 
 #ifdef __cplusplus
 }
