@@ -217,3 +217,76 @@ def test_round4_self_launched_and_world8_lines():
         assert load4(f"cpp_peer_write_world{w}.json.log")["composed_frames_equal_unsharded"] is True
     dead = load4("peer_write_dead_writer.json.log")
     assert dead["exit_codes"] == [7, 5, 7] and dead["seconds"] < 80
+
+
+# ---- round 5: the timed symbol alone (verdict Next 1), period vs latency (Next 5), the self-validating N > 1 line (Next 2)
+R5 = os.path.join(ROOT, "profiles", "r05")
+
+
+def load5(name):
+    with open(os.path.join(R5, name)) as f:
+        return json.loads(f.read().strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize("name", ["final_bench.json.log", "final_bench_steps20.json.log", "final_bench_c2.json.log", "final_bench_c4.json.log",
+                                  "final_bench_c5.json.log"])
+def test_round5_bench_line_contract(name):
+    d = load5(name)
+    for k, t in DRIVER_KEYS.items():
+        assert isinstance(d[k], t), k
+    assert d["vs_baseline"] is None and d["higher_is_better"] is True and d["unit"] == "Mrays/s" and d["n_gpus"] == 1
+    assert d["config"]["frame_equals_oracle"] is True
+    # the line says which of its figures is a period and where the latency is
+    assert "PERIOD" in d["config"]["ms_per_step_is"] and "extra.one_frame_in_flight" in d["config"]["ms_per_step_is"]
+    r = d["roofline"]
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and r["kernel_ms"] <= d["ms_per_step"] * 1.001
+    # one launch of the timed symbol alone on the chip: slower than the period, and priced on the same algorithmic bytes
+    assert r["kernel_ms_alone"] > r["kernel_ms"]
+    assert abs(r["frac_alone"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms_alone"] * 1e-3) / 1e9 / r["peak"]) < 1e-3
+    assert d["extra"]["timed_symbol_alone"]["kernel"] == r["kernel"]
+    assert d["extra"]["one_frame_in_flight"]["ms_per_step"] > d["ms_per_step"]
+    assert d["cpu_baseline"]["host"]["cgroup_quota_from"] in (None, "cgroup v2 cpu.max", "cgroup v1 cpu.cfs_quota_us / cpu.cfs_period_us")
+
+
+def test_round5_headline_quotes_a_clean_rocprof_record_of_the_timed_symbol():
+    """round-4 verdict, Next 1: 5.150 GB / that file's average / 8 TB/s reproduces roofline.frac_alone within 3 %"""
+    import csv
+    d = load5("final_bench.json.log")
+    r = d["roofline"]
+    rp = r["kernel_ms_alone_rocprof"]
+    assert rp["profile"] == "profiles/r05/final_c3_timed_symbol_alone_kernel_stats.csv" and rp["agrees_with_kernel_ms_alone_within_3pct"] is True
+    with open(os.path.join(ROOT, rp["profile"])) as f:
+        row = [x for x in csv.DictReader(f) if x["Name"].startswith("k_render")][0]
+    assert row["Name"] == r["kernel"] == "k_render_sync_pinhole_resolved" and int(row["Calls"]) >= 100
+    avg_ms = float(row["AverageNs"]) / 1e6
+    assert abs(avg_ms - rp["average_ms"]) < 1e-3
+    frac_from_file = r["algorithmic_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9 / 8000.0
+    assert abs(frac_from_file / r["frac_alone"] - 1.0) < 0.03
+    # the bench line of the profiled command itself: one launch at a time, whole-spp units, the same symbol
+    alone = load5("final_bench_timed_symbol_alone.json.log")
+    assert alone["config"]["frames_in_flight"] == 1 and alone["config"]["whole_spp_work_units"] is True
+    assert alone["roofline"]["kernel"] == r["kernel"] and abs(alone["roofline"]["kernel_ms"] / r["kernel_ms_alone"] - 1.0) < 0.03
+    # the record is the one profiles/traffic.json holds for these kernel sources
+    rec = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["entries"]["c3_n1_inflight1_wholespp"]
+    assert abs(rec["profiled_kernel_ms"] - avg_ms) < 1e-3 and rec["kernel"] == r["kernel"] and rec["settings"]["frames_in_flight"] == 1
+
+
+def test_round5_self_launched_lines_validate_themselves():
+    """round-4 verdict, Next 2: at N > 1 the GATHERED frame 0 against the oracle, and what the exchange ran on, in the line"""
+    for name, n, gather in (("self_launch_gloo4_root.json.log", 4, "root"), ("self_launch_gloo4_peer.json.log", 4, "peer"),
+                            ("self_launch_gloo2_root.json.log", 2, "root"), ("self_launch_gloo8_peer.json.log", 8, "peer")):
+        d = load5(name)
+        c = d["config"]
+        assert d["n_gpus"] == n and c["ranks_in_process_group"] == n, name
+        assert c["gathered_frame_equals_unsharded"] is True and c["frame_equals_oracle"] is True, name
+        assert f"{n} ranks" in c["frame_equals_oracle_is"] and "summed over ranks" in c["frame_equals_oracle_is"]
+        assert [p["rank"] for p in c["per_rank"]] == list(range(n)) and all(p["kernel_ms_render_only"] > 0 for p in c["per_rank"])
+        # the four ranks' rows make up the frame: their rays add up to the unsharded frame's
+        assert abs(sum(p["rays_per_frame"] for p in c["per_rank"]) - c["rays_per_frame"]) <= n      # (each is a floor of a mean over the block's frames)
+        ex = c["exchange"]
+        assert ex["backend"] == "gloo" and ex["world"] == n and ex["rccl_version"] and ex["device_can_access_peer"] == [[1]]
+        assert ex["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+        if gather == "root":
+            assert "gloo" in c["sharding"] and "REHEARSAL" in c["sharding"] and "RCCL gather" not in c["sharding"]
+        else:
+            assert "direct peer writes" in c["sharding"]
