@@ -451,6 +451,8 @@ def main():
     ap.add_argument("--lane-samples", type=int, default=0, choices=[0, 1, 4],
                     help="lane <-> (pixel, sample) map of the frame kernel (vrc_renderer_set_lane_samples): 1 = 8 x 8 pixels per wave, "
                          "4 = 4 x 4 pixels x 4 samples abreast, 0 = the library's choice")
+    ap.add_argument("--no-quad", action="store_true",
+                    help="A/B: vrc_renderer_set_quad_walks(0) -- the pinhole kernel's sample-invariant walks in the plain 8 x 8 x 1 layout")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra measurements (2-bounce extension)")
     ap.add_argument("--tuning", default="", help="blocks_per_cu: workgroups of the frame kernel per CU (= which waves-per-SIMD build), 0 = the library's choice")
     args = ap.parse_args()
@@ -545,6 +547,8 @@ def main():
             r.setSampleChunk(spp)
         if args.lane_samples:
             r.setLaneSamples(args.lane_samples)
+        if args.no_quad:
+            r.setQuadWalks(False)
         return r
 
     rcs = [make_renderer() for _ in range(F)]

@@ -105,6 +105,7 @@ SYMBOLS = {
     "vrc_renderer_set_walk_from_root": (_int, [_vp, _u32]),
     "vrc_renderer_set_lane_samples": (_int, [_vp, _u32]),
     "vrc_set_lane_samples": (_int, [_u32]),
+    "vrc_renderer_set_quad_walks": (_int, [_vp, _u32]),
     "vrc_renderer_last_kernel": (C.c_char_p, [_vp]),
     "vrc_ipc_export_image": (_int, [_vp, _vp]),
     "vrc_ipc_open_image": (_int, [_int, _vp, C.POINTER(_vp)]),

@@ -59,6 +59,7 @@ struct Tuning {
     bool reuse_invariant = false;       // pinhole camera: walk a unit's sample-invariant rays once (never a process default)
     bool walk_from_root = false;        // measurement switch: no ray starts below the root
     uint32_t lane_samples = 0;          // lane <-> (pixel, sample) map of the stage-synchronous kernel: 0 = automatic, 1, 4
+    bool quad_walks = true;             // pinhole kernels: the sample-invariant walks quadrant by quadrant where a launch allows it
 };
 Tuning g_tuning;
 std::mutex g_tuning_mu;
@@ -200,6 +201,13 @@ extern "C" int vrc_renderer_set_lane_samples(vrc_renderer* r, uint32_t samples)
     if (!r) return fail(VRC_ERR_INVALID, "null renderer");
     if (samples != 0 && samples != 1 && samples != 4) return fail(VRC_ERR_INVALID, "vrc_renderer_set_lane_samples: %u (0, 1 or 4)", samples);
     r->tuning.lane_samples = samples;
+    return VRC_OK;
+}
+extern "C" int vrc_renderer_set_quad_walks(vrc_renderer* r, uint32_t on)
+{
+    if (!r) return fail(VRC_ERR_INVALID, "null renderer");
+    if (on > 1) return fail(VRC_ERR_INVALID, "vrc_renderer_set_quad_walks: on = %u (0 or 1)", on);
+    r->tuning.quad_walks = on != 0;
     return VRC_OK;
 }
 extern "C" const char* vrc_renderer_last_kernel(const vrc_renderer* r) { return r ? r->last_kernel : ""; }
@@ -695,6 +703,27 @@ int render_impl(vrc_renderer* r, const vrc_camera* cam, const vrc_frame_params* 
                                                "use fewer samples per call or a larger sample chunk", (unsigned long long)units);
         // one wave per unit until the chip is full: a shard of few tiles still spreads over all CUs
         want = (units + VRC_RENDER_BLOCK / 64 - 1) / (VRC_RENDER_BLOCK / 64);
+    }
+    // Quadrant walks (render_sync_body's QUAD; vrc_renderer_set_quad_walks, on by default): the pinhole kernels on the 8 x 8 map
+    // when every work unit has a multiple of four samples (the walks of a pixel's sample-invariant rays are laid out four
+    // abreast), without invariant-ray reuse (one walk per unit: nothing to lay out) and without the primary-hit capture (which
+    // records per-lane complexities); the tree must have 8 levels or more (a walk's final state waits in stack rows 3..7).
+    {
+        const uint32_t c_head = a.sample_chunk ? a.sample_chunk : a.p.spp, c_tail = a.sample_chunk_tail ? a.sample_chunk_tail : c_head;
+        if (tuning.quad_walks && a.lane_samples == 1u && a.p.use_samples && a.p.spp % 4u == 0u && c_head % 4u == 0u && c_tail % 4u == 0u &&
+            !a.reuse_invariant && !a.prim && !a.walk_from_root && !a.checker_wide && vrc::camera_is_pinhole(a.cam) &&
+            s->depth >= 8u && 163840u / (2u * s->depth * 1024u + 1536u + 128u + 544u + 32u + vrc::quad_lds_bytes()) >= bpc) {
+            a.quad_walks = 1u;
+            // (its build may sit at another occupancy than the plain kernel's)
+            const uint32_t fitq = 163840u / (2u * s->depth * 1024u + 1536u + 128u + 544u + 32u + vrc::quad_lds_bytes());
+            uint32_t bq = vrc::quad_waves() < fitq ? vrc::quad_waves() : fitq;
+            if (tuning.blocks_per_cu_set && tuning.blocks_per_cu < bq) bq = tuning.blocks_per_cu;
+            const uint64_t capq = (uint64_t)s->cu_count * bq;
+            const uint32_t gridq = (uint32_t)(want < capq ? want : capq);
+            HIP_TRY(vrc::launch_render(a, gridq, st, &r->last_kernel));
+            if (queue_used >= 0) r->queue_zero[1 - queue_used] = true;
+            return VRC_OK;
+        }
     }
     const uint32_t grid = (uint32_t)(want < cap ? want : cap);
     HIP_TRY(vrc::launch_render(a, grid, st, &r->last_kernel));

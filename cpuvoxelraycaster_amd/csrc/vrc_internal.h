@@ -71,6 +71,9 @@ struct FrameArgs {
     // which lane <-> (pixel, sample) map of the stage-synchronous kernel: 1 = 8 x 8 pixels, 4 = 4 x 4 pixels x 4 samples abreast
     // (render_sync_body's NS); n_items then counts 64 lanes per 4 x 4 tile
     uint32_t lane_samples;
+    // pinhole kernels: the sample-invariant walks quadrant by quadrant, four samples abreast (render_sync_body's QUAD); the host
+    // sets it only for launches whose every unit has a multiple of four samples, without reuse and without the capture
+    uint32_t quad_walks;
     uint32_t* tile_done;
     uint32_t* resolve_dst;
     vrc_camera cam;
@@ -84,6 +87,8 @@ hipError_t launch_cast_ray_chains(const void* nodes, int depth, uint64_t n, cons
 hipError_t launch_grid_cast(const uint8_t* cells, int X, int Y, int Z, uint64_t n, const float* org, const float* dir,
                             vrc_hit* out, hipStream_t st);
 uint32_t sync_max_blocks_per_cu();    // register-limited workgroups per CU of k_render_sync
+uint32_t quad_lds_bytes();            // LDS a workgroup of the quadrant-walk kernels needs on top
+uint32_t quad_waves();                // waves per SIMD the quadrant-walk kernels are built for
 uint32_t sync_s4_waves(bool pinhole); // waves per SIMD the samples-abreast builds were compiled for
 // The stage-synchronous kernels are built for 6 waves per SIMD (80 VGPRs), the lens one-bounce kernel also for 7 (72).
 // Rounds 2 and 3 shipped 7- and 8-wave builds of the pinhole kernels too, picked by a table (profiles/r03/sweep_waves.txt:

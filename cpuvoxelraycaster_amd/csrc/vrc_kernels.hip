@@ -432,6 +432,58 @@ __device__ __forceinline__ float gi_two_levels(const uint2* __restrict__ nodes, 
     return smax(0.0f, acc0 / 1.0f);
 }
 
+// ---- Quadrant walks (round 5): the pinhole kernel's sample-invariant walks in a 4 x 4 pixels x 4 samples lane map -----------
+// With a pinhole camera a pixel's primary ray and the shadow ray of its hit are the same for every sample, and the reference
+// walks them once per sample (raycaster.hpp:131,153).  The plain pinhole kernel does that as n walks of 64 pixels x 1 sample: a
+// stage lasts as long as the longest ray of 64 neighbouring pixels.  Here the same 64 x n walks are laid out as 4 x (n / 4)
+// walks of one QUADRANT of the tile -- 16 pixels, each in four lanes (lane = pixel-in-quadrant + 16 x sample) --: every ray the
+// reference casts is still walked, each by its own lane, but a stage now lasts as long as the longest ray of 16 pixels, and a
+// round issues fewer of the loop's blocks (tests/tools/tile_shape.py: primary 1715 -> 1487, shadow 1522 -> 1216 VALU
+// instructions per wave-sample on the metric's pose).  Unlike the samples-abreast kernels (NS = 4) the set-up stays hoisted:
+// rays are generated ONCE per pixel at full lane utilisation in the 8 x 8 map and handed to the quadrant's lanes with
+// ds_bpermute (no VALU, no LDS storage); the four lanes of a pixel walk in step on the pixel's OWN stack column (identical
+// pushes to one address), so the path to the primary hit ends up where the GI stages, which keep the 8 x 8 map, expect it.
+
+constexpr uint32_t VRC_QUAD_LDS_BYTES = 0u;                           // (a walk's final state waits in the secondary stack: depth >= 8 rows)
+// the 8 x 8 map's lane of pixel q (0..15) of quadrant k (0..3)
+__device__ __forceinline__ uint32_t quad_lane(uint32_t k, uint32_t q)
+{
+    return ((k >> 1) * 4u + (q >> 2)) * 8u + (k & 1u) * 4u + (q & 3u);
+}
+
+// ctr[0] += wave_steps, ctr[1] += the lanes with `casts` set: book_walk for a call that ALL lanes of the wave make
+__device__ __forceinline__ void book_walk_of(unsigned long long* ctr, uint32_t wave_steps, bool casts)
+{
+    const unsigned long long m = __ballot(casts);
+    if ((threadIdx.x & 63u) == 0u) {
+        __hip_atomic_fetch_add(ctr + 0, (unsigned long long)wave_steps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        __hip_atomic_fetch_add(ctr + 1, (unsigned long long)__popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+}
+
+// what ray_setup + ray_start_below left in lane `src` of this wave, as this lane's ray; pk = scale | child << 5 | mirror << 8 |
+// accepted by ray_setup << 11 | casts a ray << 12 of that lane
+__device__ __forceinline__ void quad_gather(Ray& r, bool& casts, bool& active, const Ray& s, const uint32_t spk, const uint32_t src, const uint2 root)
+{
+    const int a = (int)(src << 2);
+#define VRC_QG(f) u2f((uint32_t)__builtin_amdgcn_ds_bpermute(a, (int)f2u(s.f)))
+    r.tcx = VRC_QG(tcx); r.tcy = VRC_QG(tcy); r.tcz = VRC_QG(tcz);
+    r.tox = VRC_QG(tox); r.toy = VRC_QG(toy); r.toz = VRC_QG(toz);
+    r.px = VRC_QG(px); r.py = VRC_QG(py); r.pz = VRC_QG(pz);
+    r.t_min = VRC_QG(t_min); r.t_max = VRC_QG(t_max);
+#undef VRC_QG
+    const uint32_t pk = (uint32_t)__builtin_amdgcn_ds_bpermute(a, (int)spk);
+    r.scale = (int)(pk & 31u); r.child_offset = (pk >> 5) & 7u; r.mirror = (pk >> 8) & 7u;
+    active = ((pk >> 11) & 1u) != 0u; casts = ((pk >> 12) & 1u) != 0u;
+    r.scale_f = u2f(((uint32_t)r.scale + 104u) << 23);                // 2^(scale - 23); a start below the root derives its own
+    r.h = r.t_max; r.parent_id = 0u; r.normal = 0u; r.complexity = 0u; r.kind = 0u; r.shift = 0u; r.nd = root;
+}
+
+__device__ __forceinline__ uint32_t quad_pack(const Ray& r, bool active, bool casts)
+{
+    return casts ? ((uint32_t)r.scale | (r.child_offset << 5) | (r.mirror << 8) | ((active ? 1u : 0u) << 11) | (1u << 12)) : 0u;
+}
+
 // sink of one pixel-sample, raycaster.hpp:77-91: sum in registers (sample mode; one accumulator update per unit) or
 // the 0.4 / 0.6 temporal blend into render_image
 __device__ __forceinline__ void sink_sample(const FrameArgs& a, const uint32_t pix, const uint32_t color,
@@ -469,9 +521,12 @@ __device__ __forceinline__ uint32_t albedo_of(const uint8_t* tex, const Hit& h)
 // the longest of 16 neighbouring pixels' instead of 64 and a round issues fewer of the loop's blocks -- 6-11 % fewer VALU
 // instructions in the walks of the C3 frame, 4 % with a lens (tests/tools/tile_shape.py -> profiles/r04/tile_shape.json).
 // Every ray the reference casts is still walked and counted, each by its own lane.
-template <bool PINHOLE, bool ONE_BOUNCE, bool FUSED, bool FROM_ROOT = false, uint32_t NS = 1u>
+// QUAD (pinhole, 8 x 8 map): the sample-invariant walks run quadrant by quadrant, four samples abreast (see quad_gather above);
+// for units whose sample count is a multiple of four, without invariant-ray reuse and without the primary-hit capture.
+template <bool PINHOLE, bool ONE_BOUNCE, bool FUSED, bool FROM_ROOT = false, uint32_t NS = 1u, bool QUAD = false>
 __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
 {
+    static_assert(!QUAD || (PINHOLE && !FROM_ROOT && NS == 1u), "quadrant walks exist for the pinhole kernels on the 8 x 8 map");
     // [depth][2][256] two stacks, their rows interleaved | 1536 B textures | 4 waves x 4 counters | camera paths (8 x 16 entries + 8) |
     // 4 waves' count of iterations not executed
     extern __shared__ stack_t lds_dyn[];
@@ -624,6 +679,108 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
             uint32_t albedo = 0u;                                              // | scale of the hit << 24
             float light_intensity = 0.0f;
             float hpx = 0.0f, hpy = 0.0f, hpz = 0.0f, hnx = 0.0f, hny = 0.0f, hnz = 0.0f;
+            if constexpr (QUAD) {
+                // ---- the same stages with the walks laid out quadrant by quadrant (the host guarantees n_samples % 4 == 0,
+                // no reuse, no capture).  8 x 8 map: generate the pixel's camera ray, once
+                stack_t* const stk_wave = stk - lane;                              // column of this wave's lane 0
+                // (what a pixel's walks leave for the 8 x 8 map waits in the pixel's column of the SECONDARY stack: rows 3..7 after
+                // the primary walks, which do not touch that stack; row 0 after the shadow walks of its quadrant, which are done with it)
+                const uint32_t q16 = lane & 15u;
+                Ray r0, r;
+                bool active = false;
+                float ox = 0.0f, oy = 0.0f, oz = 0.0f, dx = 0.0f, dy = 0.0f, dz = 0.0f;
+                r0.tcx = r0.tcy = r0.tcz = r0.tox = r0.toy = r0.toz = 0.0f; r0.px = r0.py = r0.pz = 1.0f; r0.t_min = r0.t_max = 0.0f;
+                r0.scale = SVO_MAX - 1; r0.child_offset = 0u; r0.mirror = 0u;
+                if (valid) {
+                    // R0: main.cpp:133,145-149; camera_controller.hpp:34-54 with rand_vec = +-0 (see PINHOLE above)
+                    const float aspect_ratio = (float)W / (float)H;
+                    const float lens_x = (float)px_x / (float)H - aspect_ratio * 0.5f;
+                    const float lens_y = (float)px_y / (float)H - 0.5f;
+                    float sx = lens_x, sy = lens_y, sz = a.cam.fov;
+                    normalize3(sx, sy, sz);
+                    float vx = sx * a.cam.focal_length, vy = sy * a.cam.focal_length, vz = sz * a.cam.focal_length;
+                    const float* m = a.cam.rot;
+                    normalize3(vx, vy, vz);
+                    dx = (m[0] * vx + m[1] * vy) + m[2] * vz;
+                    dy = (m[3] * vx + m[4] * vy) + m[5] * vz;
+                    dz = (m[6] * vx + m[7] * vy) + m[8] * vz;
+                    ox = (a.cam.position[0] + 0.0f) * inv_size + 1.0f;
+                    oy = (a.cam.position[1] + 0.0f) * inv_size + 1.0f;
+                    oz = (a.cam.position[2] + 0.0f) * inv_size + 1.0f;
+                    active = ray_setup(r0, root, ox, oy, oz, dx, dy, dz);
+                    const stack_t* const my_cam_path = cam_path + (r0.mirror ^ 7u) * 16u;
+                    ray_start_at_camera(r0, cam_scale < 22u ? my_cam_path[15] : 22u, ox, oy, oz);
+                }
+                uint32_t pk = quad_pack(r0, active, valid);
+                // (the kernel is at its register budget: what the pixel needs again after the walks waits in LDS meanwhile -- the
+                // direction in this lane's column of the secondary stack, which no primary walk touches)
+                stk[VRC_RENDER_BLOCK] = f2u(dx); stk[VRC_RENDER_BLOCK + VRC_SYNC_ROW] = f2u(dy); stk[VRC_RENDER_BLOCK + 2 * VRC_SYNC_ROW] = f2u(dz);
+                // quadrant by quadrant: the four lanes of a pixel walk its camera ray, once per sample (raycaster.hpp:131)
+#pragma unroll 1
+                for (uint32_t k = 0; k < 4u; ++k) {
+                    const uint32_t src = quad_lane(k, q16);
+                    stack_t* const col = stk_wave + src;                           // the pixel's own column, shared by its four lanes
+                    for (uint32_t rep = n_samples >> 2; rep--;) {
+                        bool casts, act;
+                        quad_gather(r, casts, act, r0, pk, src, root);
+                        copy_camera_path<VRC_SYNC_ROW>(col, cam_path + (r.mirror ^ 7u) * 16u, depth, cam_scale);
+                        book_not_executed(ctr, act, r);
+                        book_walk_of(ctr, ray_walk<0, false, true, true>(r, act, nodes, col, depth, 0.0f, 0.0f), casts);
+                    }
+                    if (lane < 16u) {                                              // (the four lanes hold the same result)
+                        stack_t* const sv = col + VRC_RENDER_BLOCK;
+                        sv[3 * VRC_SYNC_ROW] = f2u(r.px); sv[4 * VRC_SYNC_ROW] = f2u(r.py); sv[5 * VRC_SYNC_ROW] = f2u(r.pz); sv[6 * VRC_SYNC_ROW] = f2u(r.t_min);
+                        sv[7 * VRC_SYNC_ROW] = (uint32_t)r.scale | (r.child_offset << 5) | (r.normal << 8) | (r.kind << 11);
+                    }
+                }
+                if (valid) {
+                    {   // 8 x 8 map again: the state the pixel's walk ended in
+                        const stack_t* const sv = stk + VRC_RENDER_BLOCK;
+                        const uint32_t e = sv[7 * VRC_SYNC_ROW];
+                        r = r0;
+                        r.px = u2f(sv[3 * VRC_SYNC_ROW]); r.py = u2f(sv[4 * VRC_SYNC_ROW]); r.pz = u2f(sv[5 * VRC_SYNC_ROW]); r.t_min = u2f(sv[6 * VRC_SYNC_ROW]);
+                        r.scale = (int)(e & 31u); r.child_offset = (e >> 5) & 7u; r.normal = (e >> 8) & 7u; r.kind = (e >> 11) & 3u;
+                        r.scale_f = u2f(((uint32_t)r.scale + 104u) << 23);
+                        r.shift = r.child_offset ^ r.mirror; r.complexity = 0u; r.parent_id = 0u;
+                    }
+                    Hit h;
+                    ox = (a.cam.position[0] + 0.0f) * inv_size + 1.0f;
+                    oy = (a.cam.position[1] + 0.0f) * inv_size + 1.0f;
+                    oz = (a.cam.position[2] + 0.0f) * inv_size + 1.0f;
+                    dx = u2f(stk[VRC_RENDER_BLOCK]); dy = u2f(stk[VRC_RENDER_BLOCK + VRC_SYNC_ROW]); dz = u2f(stk[VRC_RENDER_BLOCK + 2 * VRC_SYNC_ROW]);
+                    ray_finish(r, depth, ox, oy, oz, dx, dy, dz, h);
+                    active = false;
+                    if (h.hit) {
+                        hit = true;
+                        albedo = albedo_of(tex, h) | (h.hit >> 16 << 24);               // raycaster.hpp:141-145
+                        hpx = h.px; hpy = h.py; hpz = h.pz; hnx = h.nx; hny = h.ny; hnz = h.nz;
+                        // raycaster.hpp:139,150-158 shadow ray(s): the reference re-casts the identical ray
+                        ox = h.px + h.nx * inv_size * 0.001f;
+                        oy = h.py + h.ny * inv_size * 0.001f;
+                        oz = h.pz + h.nz * inv_size * 0.001f;
+                        dx = lx - ox; dy = ly - oy; dz = lz - oz;
+                        normalize3(dx, dy, dz);
+                        light_intensity = smax(0.0f, dot3(dx, dy, dz, h.nx, h.ny, h.nz));       // :156 (taken back below if occluded)
+                        active = ray_setup(r0, root, ox, oy, oz, dx, dy, dz);
+                        ray_start_below(r0, start_scale_next_to(ox, oy, oz, h.px, h.py, h.pz, h.hit >> 16), ox, oy, oz);
+                    }
+                }
+                pk = quad_pack(r0, active, hit);
+#pragma unroll 1
+                for (uint32_t k = 0; k < 4u; ++k) {
+                    const uint32_t src = quad_lane(k, q16);
+                    stack_t* const col = stk_wave + src;
+                    for (uint32_t rep = (n_samples * shadow_samples) >> 2; rep--;) {
+                        bool casts, act;
+                        quad_gather(r, casts, act, r0, pk, src, root);
+                        copy_stack<VRC_SYNC_ROW>(col + VRC_RENDER_BLOCK, col, depth);
+                        book_not_executed(ctr, act, r);
+                        book_walk_of(ctr, ray_walk<0, false, true, true>(r, act, nodes, col + VRC_RENDER_BLOCK, depth, 0.0f, 0.0f), casts);
+                    }
+                    if (lane < 16u) col[VRC_RENDER_BLOCK] = r.kind;
+                }
+                if (hit && stk[VRC_RENDER_BLOCK]) light_intensity = 0.0f;                // :155-157
+            } else
             if (valid) {
                 // R0: main.cpp:133,145-149; camera_controller.hpp:34-54 with rand_vec = +-0 (see PINHOLE above)
                 const float aspect_ratio = (float)W / (float)H;
@@ -949,6 +1106,23 @@ VRC_SYNC_KERNEL_NS(k_render_sync_s4, false, true, false, VRC_SYNC_S4_WAVES_LENS,
 VRC_SYNC_KERNEL_NS(k_render_sync_resolved_s4, false, true, true, VRC_SYNC_S4_WAVES_LENS, 4u)
 VRC_SYNC_KERNEL_NS(k_render_sync_pinhole_s4, true, true, false, VRC_SYNC_S4_WAVES, 4u)
 VRC_SYNC_KERNEL_NS(k_render_sync_pinhole_resolved_s4, true, true, true, VRC_SYNC_S4_WAVES, 4u)
+// the pinhole kernels with quadrant walks (render_sync_body's QUAD)
+#if !(defined(VRC_WALK_CPP) || defined(VRC_PROBE) || defined(VRC_NO_START_BELOW))
+#define VRC_HAVE_QUAD 1
+#ifndef VRC_SYNC_Q_WAVES
+#define VRC_SYNC_Q_WAVES 6
+#endif
+#define VRC_SYNC_KERNEL_Q(name, ONE_BOUNCE, FUSED)                                                         \
+    extern "C" __global__ void __launch_bounds__(VRC_RENDER_BLOCK, VRC_SYNC_Q_WAVES) name(const FrameArgs a)  \
+    {                                                                                                      \
+        render_sync_body<true, ONE_BOUNCE, FUSED, false, 1u, true>(a);                                     \
+    }
+VRC_SYNC_KERNEL_Q(k_render_sync_pinhole_q, true, false)
+VRC_SYNC_KERNEL_Q(k_render_sync_pinhole_resolved_q, true, true)
+VRC_SYNC_KERNEL_Q(k_render_sync_pinhole2_q, false, false)
+VRC_SYNC_KERNEL_Q(k_render_sync_pinhole2_resolved_q, false, true)
+#undef VRC_SYNC_KERNEL_Q
+#endif
 #undef VRC_SYNC_KERNEL
 #undef VRC_SYNC_KERNEL_NS
 // every kernel of the 8 x 8 map once more with every ray started at the root, as lsvo.hpp:60-72 does
@@ -1157,6 +1331,8 @@ hipError_t launch_grid_cast(const uint8_t* cells, int X, int Y, int Z, uint64_t 
 }
 
 uint32_t sync_max_blocks_per_cu() { return VRC_SYNC_MIN_WAVES; }
+uint32_t quad_lds_bytes() { return VRC_QUAD_LDS_BYTES; }
+uint32_t quad_waves() { return VRC_SYNC_Q_WAVES; }
 uint32_t sync_s4_waves(bool pinhole) { return pinhole ? VRC_SYNC_S4_WAVES : VRC_SYNC_S4_WAVES_LENS; }
 uint32_t sync_waves_for(bool pinhole, bool one_bounce, bool use_gi, bool whole_spp_units, uint64_t pixel_samples, uint32_t requested)
 {
@@ -1187,14 +1363,22 @@ hipError_t launch_render(const FrameArgs& a, uint32_t grid_blocks, hipStream_t s
 {
     const char* name = "";
     {
-        const size_t lds = 2 * (size_t)a.depth * VRC_RENDER_BLOCK * sizeof(stack_t) + 1536 + 128 + VRC_CAMERA_PATH_BYTES + 32;   // two stacks, tables, the waves' counters, camera paths, iterations not executed
+        size_t lds = 2 * (size_t)a.depth * VRC_RENDER_BLOCK * sizeof(stack_t) + 1536 + 128 + VRC_CAMERA_PATH_BYTES + 32;   // two stacks, tables, the waves' counters, camera paths, iterations not executed
         const bool pinhole = camera_is_pinhole(a.cam);
         const bool one = a.p.gi_bounces <= 1u, fused = a.fused_resolve != 0u;
         const uint32_t waves = a.waves;
         struct Build { void (*fn)(const FrameArgs); const char* name; };
 #define VRC_BUILD(k) Build{k, #k}
         const bool s4 = a.lane_samples == 4u && one;
+#ifdef VRC_HAVE_QUAD
+        const bool quad = a.quad_walks != 0u && pinhole && !s4 && !a.walk_from_root;
+        if (quad) lds += VRC_QUAD_LDS_BYTES;
+#endif
         const Build b =
+#ifdef VRC_HAVE_QUAD
+            quad ? (one ? (fused ? VRC_BUILD(k_render_sync_pinhole_resolved_q) : VRC_BUILD(k_render_sync_pinhole_q))
+                        : (fused ? VRC_BUILD(k_render_sync_pinhole2_resolved_q) : VRC_BUILD(k_render_sync_pinhole2_q))) :
+#endif
             s4 ? (pinhole ? (fused ? VRC_BUILD(k_render_sync_pinhole_resolved_s4) : VRC_BUILD(k_render_sync_pinhole_s4))
                           : (fused ? VRC_BUILD(k_render_sync_resolved_s4) : VRC_BUILD(k_render_sync_s4))) :
             a.walk_from_root ? (pinhole ? (one ? (fused ? VRC_BUILD(k_render_sync_pinhole_resolved_from_root) : VRC_BUILD(k_render_sync_pinhole_from_root))

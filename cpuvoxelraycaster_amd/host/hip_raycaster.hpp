@@ -246,6 +246,7 @@ public:
     // ... and, beyond the reference, the sample-invariant primary / shadow walks of a pinhole camera done once per unit
     void setInvariantRayReuse(bool on) { check(vrc_renderer_set_invariant_ray_reuse(r_, on ? 1u : 0u), "vrc_renderer_set_invariant_ray_reuse"); }
     void setLaneSamples(uint32_t samples) { check(vrc_renderer_set_lane_samples(r_, samples), "vrc_renderer_set_lane_samples"); }
+    void setQuadWalks(bool on) { check(vrc_renderer_set_quad_walks(r_, on ? 1u : 0u), "vrc_renderer_set_quad_walks"); }
     void setWalkFromRoot(bool on) { check(vrc_renderer_set_walk_from_root(r_, on ? 1u : 0u), "vrc_renderer_set_walk_from_root"); }
 
     void samples_to_image(void* stream = nullptr) { check(vrc_samples_to_image(r_, stream), "vrc_samples_to_image"); }   // raycaster.hpp:94

@@ -223,6 +223,11 @@ class RayCaster:
         0 = the library's choice.  Same results either way.  include/vrc.h: vrc_renderer_set_lane_samples."""
         check(capi.load().vrc_renderer_set_lane_samples(self._h, samples))
 
+    def setQuadWalks(self, on=True):
+        """pinhole camera: the sample-invariant primary / shadow walks one quadrant of the tile at a time, four samples abreast (on
+        by default where a launch allows it).  Same results.  include/vrc.h: vrc_renderer_set_quad_walks."""
+        check(capi.load().vrc_renderer_set_quad_walks(self._h, 1 if on else 0))
+
     def setInvariantRayReuse(self, on=True):
         """beyond the reference: pinhole camera, walk a work unit's primary and shadow ray once instead of once per sample
         (same image; stats then count the walks executed).  include/vrc.h: vrc_renderer_set_invariant_ray_reuse."""

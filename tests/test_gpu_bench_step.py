@@ -85,14 +85,14 @@ def check(vrc, svo, nodes, textures, cam, W, H, spp, depth, kernel):
 
 
 def test_bench_step_c3_pinhole(built, heights, textures):
-    """bench.py default command (config c3): k_render_sync_pinhole_resolved"""
+    """bench.py default command (config c3): k_render_sync_pinhole_resolved_q (quadrant walks, round 5)"""
     import cpuvoxelraycaster_amd as vrc
     depth, W, H, spp = 9, 1920, 1080, 4
     svo = vrc.LSVO.fromFastNoiseTerrain(depth, seed=1337, textures=textures)
     nodes = svo.downloadNodes()
     assert nodes.tobytes() == vrc.build_terrain_lsvo(heights, depth).tobytes()
     cam = vrc.reference_camera(depth, pitch=-0.5)
-    check(vrc, svo, nodes, textures, cam, W, H, spp, depth, "k_render_sync_pinhole_resolved")
+    check(vrc, svo, nodes, textures, cam, W, H, spp, depth, "k_render_sync_pinhole_resolved_q")
 
 
 def test_bench_step_c4_dof(built, heights, textures):

@@ -71,20 +71,21 @@ def test_library_choice_at_baseline_size(textures):
     dof = vrc.reference_camera(depth, pitch=-0.5, aperture=0.5, focal_length=60.0)
     cases = [  # camera, whole-spp units, GI, spp, bounces, expected kernel
         (pin, False, True, spp, 1, "k_render_sync_pinhole_s4"),     # a launch alone on the chip: four samples abreast (round 4)
-        (pin, True, True, spp, 1, "k_render_sync_pinhole"),
-        (pin, True, False, spp, 1, "k_render_sync_pinhole"),
+        (pin, True, True, spp, 1, "k_render_sync_pinhole_q"),       # whole-spp units of four samples: quadrant walks (round 5)
+        (pin, True, False, spp, 1, "k_render_sync_pinhole_q"),
         (pin, False, False, 1, 1, "k_render_sync_pinhole"),
         (dof, False, True, spp, 1, "k_render_sync_s4"),
         (dof, True, True, spp, 1, "k_render_sync_w7"),
         (dof, False, False, spp, 1, "k_render_sync_s4"),
-        (pin, True, True, spp, 2, "k_render_sync_pinhole2"),
+        (pin, True, True, spp, 2, "k_render_sync_pinhole2_q"),
         (pin, False, True, spp, 2, "k_render_sync_pinhole2"),
         (dof, True, True, spp, 2, "k_render_sync2"),
     ]
     for cam, whole, gi, n, bounces, kernel in cases:
         a = make(vrc, svo, depth, W, H, 0, n if whole else None, gi, bounces)
         b = make(vrc, svo, depth, W, H, 6, n if whole else None, gi, bounces)
-        b.setLaneSamples(1)                                          # the 6-wave build of the 8 x 8 map
+        b.setLaneSamples(1)                                          # the 6-wave build of the 8 x 8 map,
+        b.setQuadWalks(False)                                        # ... with the plain layout of the sample-invariant walks
         a.renderFrame(cam, spp=n); b.renderFrame(cam, spp=n)
         assert a.lastKernel() == kernel, (kernel, a.lastKernel())
         assert b.lastKernel() in ("k_render_sync_pinhole", "k_render_sync", "k_render_sync_pinhole2", "k_render_sync2"), b.lastKernel()
