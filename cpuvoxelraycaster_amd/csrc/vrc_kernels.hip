@@ -445,11 +445,19 @@ __device__ __forceinline__ float gi_two_levels(const uint2* __restrict__ nodes, 
 // pushes to one address), so the path to the primary hit ends up where the GI stages, which keep the 8 x 8 map, expect it.
 
 constexpr uint32_t VRC_QUAD_LDS_BYTES = 0u;                           // (a walk's final state waits in the secondary stack: depth >= 8 rows)
-// the 8 x 8 map's lane of pixel q (0..15) of quadrant k (0..3)
-__device__ __forceinline__ uint32_t quad_lane(uint32_t k, uint32_t q)
+// A walk's pixels: a block of the 8 x 8 tile -- 4 x 4 (each pixel in 4 lanes), 4 x 2 (8 lanes) or 2 x 2 (16 lanes): the more walks a
+// pixel's ray needs (samples per unit, x shadow samples), the fewer distinct rays share a walk (C3 pose, VALU instructions per
+// tile-sample, primary + shadow: 8 x 8 x 1 3518, 4 x 4 x 4 2926, 2 x 2 x 16 2503; tests/tools/path_schedule.py --quad).
+// lg = log2 of the lanes per pixel (2, 3 or 4).  The 8 x 8 map's lane of pixel q of block k:
+__device__ __forceinline__ uint32_t quad_lane(uint32_t k, uint32_t q, uint32_t lg)
 {
-    return ((k >> 1) * 4u + (q >> 2)) * 8u + (k & 1u) * 4u + (q & 3u);
+    const uint32_t bw_lg = lg == 4u ? 1u : 2u, bh_lg = lg == 2u ? 2u : 1u;     // block = 2^bw_lg x 2^bh_lg pixels
+    const uint32_t kx = k & ((8u >> bw_lg) - 1u), ky = k >> (3u - bw_lg);
+    const uint32_t qx = q & ((1u << bw_lg) - 1u), qy = q >> bw_lg;
+    return (((ky << bh_lg) + qy) << 3) + (kx << bw_lg) + qx;
 }
+// how many lanes a pixel's ray gets when it has to be walked n times (n % 4 == 0): log2
+__device__ __forceinline__ uint32_t quad_lanes_lg(uint32_t n) { return (n & 15u) == 0u ? 4u : ((n & 7u) == 0u ? 3u : 2u); }
 
 // ctr[0] += wave_steps, ctr[1] += the lanes with `casts` set: book_walk for a call that ALL lanes of the wave make
 __device__ __forceinline__ void book_walk_of(unsigned long long* ctr, uint32_t wave_steps, bool casts)
@@ -685,7 +693,9 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
                 stack_t* const stk_wave = stk - lane;                              // column of this wave's lane 0
                 // (what a pixel's walks leave for the 8 x 8 map waits in the pixel's column of the SECONDARY stack: rows 3..7 after
                 // the primary walks, which do not touch that stack; row 0 after the shadow walks of its quadrant, which are done with it)
-                const uint32_t q16 = lane & 15u;
+                // lanes per pixel in the primary walks (the unit's samples) and in the shadow walks (x shadow samples): 4, 8 or 16
+                const uint32_t lg_p = __builtin_amdgcn_readfirstlane(quad_lanes_lg(n_samples));
+                const uint32_t lg_s = __builtin_amdgcn_readfirstlane(quad_lanes_lg(n_samples * shadow_samples));
                 Ray r0, r;
                 bool active = false;
                 float ox = 0.0f, oy = 0.0f, oz = 0.0f, dx = 0.0f, dy = 0.0f, dz = 0.0f;
@@ -717,17 +727,17 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
                 stk[VRC_RENDER_BLOCK] = f2u(dx); stk[VRC_RENDER_BLOCK + VRC_SYNC_ROW] = f2u(dy); stk[VRC_RENDER_BLOCK + 2 * VRC_SYNC_ROW] = f2u(dz);
                 // quadrant by quadrant: the four lanes of a pixel walk its camera ray, once per sample (raycaster.hpp:131)
 #pragma unroll 1
-                for (uint32_t k = 0; k < 4u; ++k) {
-                    const uint32_t src = quad_lane(k, q16);
-                    stack_t* const col = stk_wave + src;                           // the pixel's own column, shared by its four lanes
-                    for (uint32_t rep = n_samples >> 2; rep--;) {
+                for (uint32_t k = 0; k < (1u << lg_p); ++k) {                      // (as many blocks as lanes per pixel)
+                    const uint32_t src = quad_lane(k, lane & ((64u >> lg_p) - 1u), lg_p);
+                    stack_t* const col = stk_wave + src;                           // the pixel's own column, shared by its lanes
+                    for (uint32_t rep = n_samples >> lg_p; rep--;) {
                         bool casts, act;
                         quad_gather(r, casts, act, r0, pk, src, root);
                         copy_camera_path<VRC_SYNC_ROW>(col, cam_path + (r.mirror ^ 7u) * 16u, depth, cam_scale);
                         book_not_executed(ctr, act, r);
                         book_walk_of(ctr, ray_walk<0, false, true, true>(r, act, nodes, col, depth, 0.0f, 0.0f), casts);
                     }
-                    if (lane < 16u) {                                              // (the four lanes hold the same result)
+                    if (lane < (64u >> lg_p)) {                                    // (a pixel's lanes hold the same result)
                         stack_t* const sv = col + VRC_RENDER_BLOCK;
                         sv[3 * VRC_SYNC_ROW] = f2u(r.px); sv[4 * VRC_SYNC_ROW] = f2u(r.py); sv[5 * VRC_SYNC_ROW] = f2u(r.pz); sv[6 * VRC_SYNC_ROW] = f2u(r.t_min);
                         sv[7 * VRC_SYNC_ROW] = (uint32_t)r.scale | (r.child_offset << 5) | (r.normal << 8) | (r.kind << 11);
@@ -767,17 +777,17 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
                 }
                 pk = quad_pack(r0, active, hit);
 #pragma unroll 1
-                for (uint32_t k = 0; k < 4u; ++k) {
-                    const uint32_t src = quad_lane(k, q16);
+                for (uint32_t k = 0; k < (1u << lg_s); ++k) {
+                    const uint32_t src = quad_lane(k, lane & ((64u >> lg_s) - 1u), lg_s);
                     stack_t* const col = stk_wave + src;
-                    for (uint32_t rep = (n_samples * shadow_samples) >> 2; rep--;) {
+                    for (uint32_t rep = (n_samples * shadow_samples) >> lg_s; rep--;) {
                         bool casts, act;
                         quad_gather(r, casts, act, r0, pk, src, root);
                         copy_stack<VRC_SYNC_ROW>(col + VRC_RENDER_BLOCK, col, depth);
                         book_not_executed(ctr, act, r);
                         book_walk_of(ctr, ray_walk<0, false, true, true>(r, act, nodes, col + VRC_RENDER_BLOCK, depth, 0.0f, 0.0f), casts);
                     }
-                    if (lane < 16u) col[VRC_RENDER_BLOCK] = r.kind;
+                    if (lane < (64u >> lg_s)) col[VRC_RENDER_BLOCK] = r.kind;
                 }
                 if (hit && stk[VRC_RENDER_BLOCK]) light_intensity = 0.0f;                // :155-157
             } else

@@ -126,6 +126,9 @@ def main():
     ap.add_argument("--threads", type=int, default=os.cpu_count() or 1)
     ap.add_argument("--from-root", action="store_true", help="every ray from the root (the reference's walk, the kernels before round 3)")
     ap.add_argument("--dump", default="", help="write the block issue frequencies of the shipped policy as JSON (tools/issue_model.py reads it)")
+    ap.add_argument("--quad", action="store_true",
+                    help="the pinhole kernel's quadrant walks (round 5): the primary and the shadow stage are walked one 4 x 4 quadrant of "
+                         "the tile at a time, each pixel's ray in four lanes (per tile-sample: four walks of 16 distinct rays instead of one of 64)")
     a = ap.parse_args()
     import cpuvoxelraycaster_amd as vrc
     import oracle_lib as O
@@ -175,7 +178,7 @@ def main():
     tot = {k: np.zeros(4) for k in policies}
     rounds = {k: np.zeros(4) for k in policies}
     shipped = "now (pop whenever a lane needs it)"
-    stage_blocks = np.zeros((4, 4), np.int64)       # [stage][header, descend, advance, pop] of the shipped policy
+    stage_blocks = np.zeros((4, 4), np.float64)     # [stage][header, descend, advance, pop] of the shipped policy
     lane_iters = np.zeros(4, np.int64)
     lane_skipped = np.zeros(4, np.int64)
     for (b, tx) in tiles:
@@ -185,19 +188,30 @@ def main():
             sk = skip[b * 8:b * 8 + 8, tx * 8:tx * 8 + 8, st].reshape(64)
             lane_iters[st] += (ln - np.minimum(sk, ln)).sum()
             lane_skipped[st] += np.minimum(sk, ln).sum()
+            # the lanes of one walk: the whole tile, or (quadrant walks, sample-invariant stages) one quadrant -- its 16 rays stand
+            # for 64 lanes, four identical copies each, which changes neither the rounds nor which blocks a round issues
+            if a.quad and st < 2:
+                lanes = np.arange(64).reshape(8, 8)
+                groups = [lanes[qy * 4:qy * 4 + 4, qx * 4:qx * 4 + 4].reshape(-1) for qy in range(2) for qx in range(2)]
+            else:
+                groups = [np.arange(64)]
+            # (a quadrant walk covers 16 pixels x 4 samples = one tile-sample's worth of rays: per tile-sample the stage costs the
+            # MEAN of the four quadrants' walks)
             for k, pol in policies.items():
                 pol.pop("_blocks", None)
-                c, r = simulate(o, ln, pol, lod=st >= 2, start=sk)
-                tot[k][st] += c
-                rounds[k][st] += r
+                for g in groups:
+                    c, r = simulate(o[g], ln[g], pol, lod=st >= 2, start=sk[g])
+                    tot[k][st] += c / len(groups)
+                    rounds[k][st] += r / len(groups)
                 if k == shipped:
-                    stage_blocks[st] += pol["_blocks"]
+                    stage_blocks[st] += pol["_blocks"] / float(len(groups))
     if a.dump:
         import json
-        doc = {"workload": "c3: 512^3 terrain, 1920x1080, GI, pitch -0.5, one sample of every pixel of the sampled tiles",
+        doc = {"workload": "c3: 512^3 terrain, 1920x1080, GI, pitch -0.5, one sample of every pixel of the sampled tiles"
+                           + ("; primary and shadow stage as quadrant walks (4 walks of a 4 x 4 quadrant per tile-sample)" if a.quad else ""),
                "tiles": len(tiles), "band": a.band,
-               "stages": {names[i]: {"header": int(stage_blocks[i][0]), "descend": int(stage_blocks[i][1]),
-                                     "advance": int(stage_blocks[i][2]), "pop": int(stage_blocks[i][3]),
+               "stages": {names[i]: {"header": int(round(stage_blocks[i][0])), "descend": int(round(stage_blocks[i][1])),
+                                     "advance": int(round(stage_blocks[i][2])), "pop": int(round(stage_blocks[i][3])),
                                      "starts": len(tiles), "lane_iterations": int(lane_iters[i]),
                                      "lane_iterations_not_executed": int(lane_skipped[i])} for i in range(4)},
                "camera_start_scale": int(cam_scale),

@@ -33,6 +33,8 @@ def period(N, F, whole):
             rc.setSampleChunk(spp)
         if LANE_SAMPLES:
             rc.setLaneSamples(LANE_SAMPLES)
+        if os.environ.get("VRC_QUAD_OFF") == "1":
+            rc.setQuadWalks(False)                  # A/B of the quadrant walks (round 5)
         if BLOCKS:
             rc.setTuning(blocks_per_cu=BLOCKS)      # force the 6 / 7 / 8 waves-per-SIMD build (A/B of sync_waves_for's choice)
         rcs.append(rc)
