@@ -99,6 +99,28 @@ __device__ __forceinline__ walk_rsrc_t walk_node_rsrc(const uint2* __restrict__ 
     "s_cbranch_execnz Lwalk_start%=\n"                                                          \
     "s_mov_b64 exec, %[srun]\n"
 
+// The rest of the header.  The node is only needed for the child / leaf bits; everything about the exits (c, tc) is not: with
+// VRC_WALK_LATE_WAIT the wait for the node load comes after them (more of a pop's load latency hidden; A/B, round 5).
+#ifdef VRC_WALK_LATE_WAIT
+#define VRC_WALK_HEADER_REST                                                                    \
+    "v_sub_f32_e32 %[cx], %[cx], %[tox]\n"                                                      \
+    "v_sub_f32_e32 %[cy], %[cy], %[toy]\n"                                                      \
+    "v_sub_f32_e32 %[cz], %[cz], %[toz]\n"                                                      \
+    "v_min3_f32 %[tc], %[cx], %[cy], %[cz]\n"   /* :77 */                                       \
+    "s_waitcnt vmcnt(0)\n"                      /* node of the current parent */                \
+    "v_lshrrev_b32_e32 %[m], %[kind], v46\n"      /* bit 8: child, bit 16: leaf */                \
+    "v_and_b32_e32 %[t], 0x10100, %[m]\n"       /* leaf_mask is a subset of child_mask (k_sanitize_nodes): 0, 0x100 or 0x10100 */
+#else
+#define VRC_WALK_HEADER_REST                                                                    \
+    "s_waitcnt vmcnt(0)\n"                      /* node of the current parent */                \
+    "v_lshrrev_b32_e32 %[m], %[kind], v46\n"      /* bit 8: child, bit 16: leaf */                \
+    "v_sub_f32_e32 %[cx], %[cx], %[tox]\n"                                                      \
+    "v_sub_f32_e32 %[cy], %[cy], %[toy]\n"                                                      \
+    "v_sub_f32_e32 %[cz], %[cz], %[toz]\n"                                                      \
+    "v_and_b32_e32 %[t], 0x10100, %[m]\n"       /* leaf_mask is a subset of child_mask (k_sanitize_nodes): 0, 0x100 or 0x10100 */ \
+    "v_min3_f32 %[tc], %[cx], %[cy], %[cz]\n"   /* :77 */
+#endif
+
 // v46:47 node
 #define VRC_WALK_ASM(SPANPART, COUNTPART, STARTPART, ROWSH, ROWDOWN)                                           \
     "s_mov_b64 %[sentry], exec\n"                                                               \
@@ -117,13 +139,7 @@ __device__ __forceinline__ walk_rsrc_t walk_node_rsrc(const uint2* __restrict__ 
     "v_mul_f32_e32 %[cx], %[px], %[tcx]\n"      /* :76 */                                       \
     "v_mul_f32_e32 %[cy], %[py], %[tcy]\n"                                                      \
     "v_mul_f32_e32 %[cz], %[pz], %[tcz]\n"                                                      \
-    "s_waitcnt vmcnt(0)\n"                      /* node of the current parent */                \
-    "v_lshrrev_b32_e32 %[m], %[kind], v46\n"      /* bit 8: child, bit 16: leaf */                \
-    "v_sub_f32_e32 %[cx], %[cx], %[tox]\n"                                                      \
-    "v_sub_f32_e32 %[cy], %[cy], %[toy]\n"                                                      \
-    "v_sub_f32_e32 %[cz], %[cz], %[toz]\n"                                                      \
-    "v_and_b32_e32 %[t], 0x10100, %[m]\n"       /* leaf_mask is a subset of child_mask (k_sanitize_nodes): 0, 0x100 or 0x10100 */ \
-    "v_min3_f32 %[tc], %[cx], %[cy], %[cz]\n"   /* :77 */                                       \
+    VRC_WALK_HEADER_REST                                                                        \
     SPANPART                                                                                    \
     "v_cmp_lt_u32_e32 vcc, 0x100, %[t]\n"       /* child and leaf, among the lanes inside: leaf hit :90-94 */ \
     "s_or_b64 %[sleaf], %[sleaf], vcc\n"                                                        \
