@@ -257,7 +257,7 @@ def test_round5_headline_quotes_a_clean_rocprof_record_of_the_timed_symbol():
     assert rp["profile"] == "profiles/r05/final_c3_timed_symbol_alone_kernel_stats.csv" and rp["agrees_with_kernel_ms_alone_within_3pct"] is True
     with open(os.path.join(ROOT, rp["profile"])) as f:
         row = [x for x in csv.DictReader(f) if x["Name"].startswith("k_render")][0]
-    assert row["Name"] == r["kernel"] == "k_render_sync_pinhole_resolved" and int(row["Calls"]) >= 100
+    assert row["Name"] == r["kernel"] == "k_render_sync_pinhole_resolved_q" and int(row["Calls"]) >= 100      # (quadrant walks: the default since round 5)
     avg_ms = float(row["AverageNs"]) / 1e6
     assert abs(avg_ms - rp["average_ms"]) < 1e-3
     frac_from_file = r["algorithmic_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9 / 8000.0
