@@ -76,6 +76,10 @@ def main():
             # executed, same frame; anything else: no effect at all)
             reuse = bool(rng.integers(0, 4) == 0)
             rc.setInvariantRayReuse(reuse)
+            # the quadrant walks of the pinhole kernels (on by default where a launch allows it: trees of 8+ levels, units of a
+            # multiple of four samples): a third of the cases with the plain layout instead
+            if rng.integers(0, 3) == 0:
+                rc.setQuadWalks(False)
             # the 6 / 7 / 8 waves-per-SIMD builds of the stage-synchronous kernel (0 = the library's choice)
             blocks = int(rng.choice([0, 0, 6, 7, 8]))
             if blocks:
