@@ -33,7 +33,7 @@ def render(rc, quad, fn):
     fn(rc)
 
 
-@pytest.mark.parametrize("spp,chunk,shadows", [(4, 4, 1), (8, 8, 1), (8, 4, 1), (16, 16, 1), (4, 4, 2), (12, 4, 1), (16, 8, 1), (8, 8, 2)])
+@pytest.mark.parametrize("spp,chunk,shadows", [(4, 4, 1), (8, 8, 1), (8, 4, 1), (16, 16, 1), (4, 4, 2), (12, 4, 1), (16, 8, 1), (8, 8, 2), (4, 4, 4), (8, 8, 0)])
 @pytest.mark.parametrize("size", [(200, 100), (161, 93), (17, 9), (7, 5)])
 def test_quadrant_walks_equal_the_plain_kernel(scene, size, spp, chunk, shadows):
     import torch
