@@ -708,24 +708,20 @@ int render_impl(vrc_renderer* r, const vrc_camera* cam, const vrc_frame_params* 
     // when every work unit has a multiple of four samples (the walks of a pixel's sample-invariant rays are laid out four
     // abreast), without invariant-ray reuse (one walk per unit: nothing to lay out) and without the primary-hit capture (which
     // records per-lane complexities); the tree must have 8 levels or more (a walk's final state waits in stack rows 3..7).
+    uint64_t cap_launch = cap;
     {
         const uint32_t c_head = a.sample_chunk ? a.sample_chunk : a.p.spp, c_tail = a.sample_chunk_tail ? a.sample_chunk_tail : c_head;
         if (tuning.quad_walks && a.lane_samples == 1u && a.p.use_samples && a.p.spp % 4u == 0u && c_head % 4u == 0u && c_tail % 4u == 0u &&
-            !a.reuse_invariant && !a.prim && !a.walk_from_root && !a.checker_wide && vrc::camera_is_pinhole(a.cam) &&
-            s->depth >= 8u && 163840u / (2u * s->depth * 1024u + 1536u + 128u + 544u + 32u + vrc::quad_lds_bytes()) >= bpc) {
+            !a.reuse_invariant && !a.prim && !a.walk_from_root && !a.checker_wide && vrc::camera_is_pinhole(a.cam) && s->depth >= 8u) {
             a.quad_walks = 1u;
-            // (its build may sit at another occupancy than the plain kernel's)
+            // (its builds sit at their own occupancy, whatever the plain kernel of this launch would have had)
             const uint32_t fitq = 163840u / (2u * s->depth * 1024u + 1536u + 128u + 544u + 32u + vrc::quad_lds_bytes());
             uint32_t bq = vrc::quad_waves() < fitq ? vrc::quad_waves() : fitq;
             if (tuning.blocks_per_cu_set && tuning.blocks_per_cu < bq) bq = tuning.blocks_per_cu;
-            const uint64_t capq = (uint64_t)s->cu_count * bq;
-            const uint32_t gridq = (uint32_t)(want < capq ? want : capq);
-            HIP_TRY(vrc::launch_render(a, gridq, st, &r->last_kernel));
-            if (queue_used >= 0) r->queue_zero[1 - queue_used] = true;
-            return VRC_OK;
+            cap_launch = (uint64_t)s->cu_count * bq;
         }
     }
-    const uint32_t grid = (uint32_t)(want < cap ? want : cap);
+    const uint32_t grid = (uint32_t)(want < cap_launch ? want : cap_launch);
     HIP_TRY(vrc::launch_render(a, grid, st, &r->last_kernel));
     if (queue_used >= 0) r->queue_zero[1 - queue_used] = true;           // zeroed by the launch that is now in the stream
     return VRC_OK;
