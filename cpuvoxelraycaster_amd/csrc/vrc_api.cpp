@@ -810,6 +810,7 @@ struct vrc_ipc_flags {
     uint32_t* dev = nullptr;      // the same words as the device sees them
     bool owner = false;
     bool unlinked = false;        // the creator has removed the name already (vrc_ipc_flags_unlink)
+    bool drain_failed = false;    // a stream of this process did not drain within the cap after the exchange was given up
     char name[96] = {0};
 };
 // the segment: `count` flags, then four words of header {magic, owner's pid, count, given up}
@@ -954,12 +955,20 @@ extern "C" int vrc_ipc_stream_wait(vrc_ipc_flags* f, void* stream, const int32_t
     // stream; bounded, in case the device itself is gone).
     __atomic_store_n(f->host + f->count + FLAGS_HDR_GIVEN_UP, 1u, __ATOMIC_RELEASE);
     const auto t1 = std::chrono::steady_clock::now();
+    // (bounded: 20 s for the first stream of this process that does not drain -- the device itself may be gone, or busy tearing
+    // the dead process down --, 2 s for every one after it, so that a process with several streams still leaves within half a minute)
+    const long long cap_ms = f->drain_failed ? 2000 : 20000;
+    bool drained = false;
     for (;;) {
         for (uint32_t i = 0; i < f->count; ++i) __atomic_store_n(f->host + i, 0xffffffffu, __ATOMIC_RELEASE);
-        if (hipStreamQuery((hipStream_t)stream) != hipErrorNotReady) break;
-        if (std::chrono::duration_cast<std::chrono::seconds>(std::chrono::steady_clock::now() - t1).count() >= 20) break;
+        if (hipStreamQuery((hipStream_t)stream) != hipErrorNotReady) { drained = true; break; }
+        if (std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t1).count() >= cap_ms) break;
         std::this_thread::sleep_for(std::chrono::microseconds(100));
     }
+    if (!drained) f->drain_failed = true;
+    // once more behind the last operation of this stream: a flag write that was still queued may have landed after the last
+    // store above and put an ordinary frame number back, on which another process's later wait would block again
+    for (uint32_t i = 0; i < f->count; ++i) __atomic_store_n(f->host + i, 0xffffffffu, __ATOMIC_RELEASE);
     return fail(VRC_ERR_PEER, "vrc_ipc_stream_wait: %s (pid %d); every wait on %s was released, frames after this are not valid", why, (int)who, f->name);
 }
 

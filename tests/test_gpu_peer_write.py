@@ -132,7 +132,7 @@ def test_cpp_host_dead_writer(built, tmp_path):
                          env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PW_DIE_RANK="2", PW_DIE_AT_FRAME="5"),
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
     try:
-        out, err = p.communicate(timeout=90)
+        out, err = p.communicate(timeout=150)
     except subprocess.TimeoutExpired:
         os.killpg(p.pid, 9)
         raise AssertionError("peer_write_main hung on the dead writer's flag")
