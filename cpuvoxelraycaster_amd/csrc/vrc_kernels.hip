@@ -696,7 +696,7 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
                 // lanes per pixel in the primary walks (the unit's samples) and in the shadow walks (x shadow samples): 4, 8 or 16
                 const uint32_t lg_p = __builtin_amdgcn_readfirstlane(quad_lanes_lg(n_samples));
                 const uint32_t lg_s = __builtin_amdgcn_readfirstlane(quad_lanes_lg(n_samples * shadow_samples));
-                Ray r0, r;
+                Ray r0;
                 bool active = false;
                 float ox = 0.0f, oy = 0.0f, oz = 0.0f, dx = 0.0f, dy = 0.0f, dz = 0.0f;
                 r0.tcx = r0.tcy = r0.tcz = r0.tox = r0.toy = r0.toz = 0.0f; r0.px = r0.py = r0.pz = 1.0f; r0.t_min = r0.t_max = 0.0f;
@@ -730,13 +730,17 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
                 for (uint32_t k = 0; k < (1u << lg_p); ++k) {                      // (as many blocks as lanes per pixel)
                     const uint32_t src = quad_lane(k, lane & ((64u >> lg_p) - 1u), lg_p);
                     stack_t* const col = stk_wave + src;                           // the pixel's own column, shared by its lanes
-                    for (uint32_t rep = n_samples >> lg_p; rep--;) {
+                    // (a block's ray lives in the block's iteration only, and the walks run at least once: otherwise the compiler
+                    // carries `r` round the unit loop and spills it -- 8 scratch stores and loads per unit, found in the ISA)
+                    Ray r;
+                    uint32_t rep = n_samples >> lg_p;
+                    do {
                         bool casts, act;
                         quad_gather(r, casts, act, r0, pk, src, root);
                         copy_camera_path<VRC_SYNC_ROW>(col, cam_path + (r.mirror ^ 7u) * 16u, depth, cam_scale);
                         book_not_executed(ctr, act, r);
                         book_walk_of(ctr, ray_walk<0, false, true, true>(r, act, nodes, col, depth, 0.0f, 0.0f), casts);
-                    }
+                    } while (--rep);
                     if (lane < (64u >> lg_p)) {                                    // (a pixel's lanes hold the same result)
                         stack_t* const sv = col + VRC_RENDER_BLOCK;
                         sv[3 * VRC_SYNC_ROW] = f2u(r.px); sv[4 * VRC_SYNC_ROW] = f2u(r.py); sv[5 * VRC_SYNC_ROW] = f2u(r.pz); sv[6 * VRC_SYNC_ROW] = f2u(r.t_min);
@@ -744,10 +748,10 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
                     }
                 }
                 if (valid) {
-                    {   // 8 x 8 map again: the state the pixel's walk ended in
+                    Ray r = r0;                                                    // 8 x 8 map again: the state the pixel's walk ended in
+                    {
                         const stack_t* const sv = stk + VRC_RENDER_BLOCK;
                         const uint32_t e = sv[7 * VRC_SYNC_ROW];
-                        r = r0;
                         r.px = u2f(sv[3 * VRC_SYNC_ROW]); r.py = u2f(sv[4 * VRC_SYNC_ROW]); r.pz = u2f(sv[5 * VRC_SYNC_ROW]); r.t_min = u2f(sv[6 * VRC_SYNC_ROW]);
                         r.scale = (int)(e & 31u); r.child_offset = (e >> 5) & 7u; r.normal = (e >> 8) & 7u; r.kind = (e >> 11) & 3u;
                         r.scale_f = u2f(((uint32_t)r.scale + 104u) << 23);
@@ -780,13 +784,15 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
                 for (uint32_t k = 0; k < (1u << lg_s); ++k) {
                     const uint32_t src = quad_lane(k, lane & ((64u >> lg_s) - 1u), lg_s);
                     stack_t* const col = stk_wave + src;
-                    for (uint32_t rep = (n_samples * shadow_samples) >> lg_s; rep--;) {
+                    Ray r;
+                    uint32_t rep = (n_samples * shadow_samples) >> lg_s;
+                    do {
                         bool casts, act;
                         quad_gather(r, casts, act, r0, pk, src, root);
                         copy_stack<VRC_SYNC_ROW>(col + VRC_RENDER_BLOCK, col, depth);
                         book_not_executed(ctr, act, r);
                         book_walk_of(ctr, ray_walk<0, false, true, true>(r, act, nodes, col + VRC_RENDER_BLOCK, depth, 0.0f, 0.0f), casts);
-                    }
+                    } while (--rep);
                     if (lane < (64u >> lg_s)) col[VRC_RENDER_BLOCK] = r.kind;
                 }
                 if (hit && stk[VRC_RENDER_BLOCK]) light_intensity = 0.0f;                // :155-157
