@@ -405,8 +405,8 @@ int vrc_set_lane_samples(uint32_t samples);                 /* the process defau
  * (raycaster.hpp:131,153).  on = 1: where a launch allows it the pinhole kernels lay those walks out
  * as one quadrant of the 8 x 8 tile at a time, 16 pixels with their four samples side by side in the
  * wave, instead of 64 pixels with one sample -- every ray is still walked, each by its own lane, but a
- * stage lasts as long as the longest ray of 16 neighbouring pixels instead of 64 (C3: 6.6 % fewer
- * instructions, 4.6 % less time).  Applies to sample-mode frames on the 8 x 8 lane map whose work
+ * stage lasts as long as the longest ray of 16 neighbouring pixels instead of 64 (C3: 6.5 % fewer
+ * instructions, 5.5 % less time; 16 spp: 11 %).  Applies to sample-mode frames on the 8 x 8 lane map whose work
  * units all have a multiple of four samples (spp and the sample chunk multiples of four), without
  * invariant-ray reuse and primary-hit capture, on trees of 8 levels or more; every other launch runs
  * the plain kernels (vrc_renderer_last_kernel ends in "_q" when it applied).  on = 0: never.  Image,
