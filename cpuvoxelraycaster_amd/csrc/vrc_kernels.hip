@@ -691,6 +691,12 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
                 // ---- the same stages with the walks laid out quadrant by quadrant (the host guarantees n_samples % 4 == 0,
                 // no reuse, no capture).  8 x 8 map: generate the pixel's camera ray, once
                 stack_t* const stk_wave = stk - lane;                              // column of this wave's lane 0
+                // the camera block: ONE scalar load of 16 dwords from the kernel-argument segment, live in this prologue only
+                typedef uint32_t cam16_t __attribute__((ext_vector_type(16)));
+                cam16_t cw;
+                asm volatile("s_load_dwordx16 %0, %1, %2\n s_waitcnt lgkmcnt(0)" : "=s"(cw) : "s"((const void*)ka), "i"((int)__builtin_offsetof(FrameArgs, cam)));
+                const float cpos0 = u2f(cw[0]), cpos1 = u2f(cw[1]), cpos2 = u2f(cw[2]);
+                const float cfov = u2f(cw[12]), cfocal = u2f(cw[14]);
                 // (what a pixel's walks leave for the 8 x 8 map waits in the pixel's column of the SECONDARY stack: rows 3..7 after
                 // the primary walks, which do not touch that stack; row 0 after the shadow walks of its quadrant, which are done with it)
                 // lanes per pixel in the primary walks (the unit's samples) and in the shadow walks (x shadow samples): 4, 8 or 16
@@ -706,17 +712,17 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
                     const float aspect_ratio = (float)W / (float)H;
                     const float lens_x = (float)px_x / (float)H - aspect_ratio * 0.5f;
                     const float lens_y = (float)px_y / (float)H - 0.5f;
-                    float sx = lens_x, sy = lens_y, sz = a.cam.fov;
+                    float sx = lens_x, sy = lens_y, sz = cfov;
                     normalize3(sx, sy, sz);
-                    float vx = sx * a.cam.focal_length, vy = sy * a.cam.focal_length, vz = sz * a.cam.focal_length;
-                    const float* m = a.cam.rot;
+                    float vx = sx * cfocal, vy = sy * cfocal, vz = sz * cfocal;
+                    const float m[9] = {u2f(cw[3]), u2f(cw[4]), u2f(cw[5]), u2f(cw[6]), u2f(cw[7]), u2f(cw[8]), u2f(cw[9]), u2f(cw[10]), u2f(cw[11])};
                     normalize3(vx, vy, vz);
                     dx = (m[0] * vx + m[1] * vy) + m[2] * vz;
                     dy = (m[3] * vx + m[4] * vy) + m[5] * vz;
                     dz = (m[6] * vx + m[7] * vy) + m[8] * vz;
-                    ox = (a.cam.position[0] + 0.0f) * inv_size + 1.0f;
-                    oy = (a.cam.position[1] + 0.0f) * inv_size + 1.0f;
-                    oz = (a.cam.position[2] + 0.0f) * inv_size + 1.0f;
+                    ox = (cpos0 + 0.0f) * inv_size + 1.0f;
+                    oy = (cpos1 + 0.0f) * inv_size + 1.0f;
+                    oz = (cpos2 + 0.0f) * inv_size + 1.0f;
                     active = ray_setup(r0, root, ox, oy, oz, dx, dy, dz);
                     const stack_t* const my_cam_path = cam_path + (r0.mirror ^ 7u) * 16u;
                     ray_start_at_camera(r0, cam_scale < 22u ? my_cam_path[15] : 22u, ox, oy, oz);
@@ -758,9 +764,9 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
                         r.shift = r.child_offset ^ r.mirror; r.complexity = 0u; r.parent_id = 0u;
                     }
                     Hit h;
-                    ox = (a.cam.position[0] + 0.0f) * inv_size + 1.0f;
-                    oy = (a.cam.position[1] + 0.0f) * inv_size + 1.0f;
-                    oz = (a.cam.position[2] + 0.0f) * inv_size + 1.0f;
+                    ox = (cpos0 + 0.0f) * inv_size + 1.0f;
+                    oy = (cpos1 + 0.0f) * inv_size + 1.0f;
+                    oz = (cpos2 + 0.0f) * inv_size + 1.0f;
                     dx = u2f(stk[VRC_RENDER_BLOCK]); dy = u2f(stk[VRC_RENDER_BLOCK + VRC_SYNC_ROW]); dz = u2f(stk[VRC_RENDER_BLOCK + 2 * VRC_SYNC_ROW]);
                     ray_finish(r, depth, ox, oy, oz, dx, dy, dz, h);
                     active = false;
@@ -798,21 +804,24 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
                 if (hit && stk[VRC_RENDER_BLOCK]) light_intensity = 0.0f;                // :155-157
             } else
             if (valid) {
+                typedef uint32_t cam16_t __attribute__((ext_vector_type(16)));      // (the camera block: see the quadrant-walk prologue)
+                cam16_t cw;
+                asm volatile("s_load_dwordx16 %0, %1, %2\n s_waitcnt lgkmcnt(0)" : "=s"(cw) : "s"((const void*)ka), "i"((int)__builtin_offsetof(FrameArgs, cam)));
                 // R0: main.cpp:133,145-149; camera_controller.hpp:34-54 with rand_vec = +-0 (see PINHOLE above)
                 const float aspect_ratio = (float)W / (float)H;
                 const float lens_x = (float)px_x / (float)H - aspect_ratio * 0.5f;
                 const float lens_y = (float)px_y / (float)H - 0.5f;
-                float sx = lens_x, sy = lens_y, sz = a.cam.fov;
+                float sx = lens_x, sy = lens_y, sz = u2f(cw[12]);
                 normalize3(sx, sy, sz);
-                float vx = sx * a.cam.focal_length, vy = sy * a.cam.focal_length, vz = sz * a.cam.focal_length;
-                const float* m = a.cam.rot;
+                float vx = sx * u2f(cw[14]), vy = sy * u2f(cw[14]), vz = sz * u2f(cw[14]);
+                const float m[9] = {u2f(cw[3]), u2f(cw[4]), u2f(cw[5]), u2f(cw[6]), u2f(cw[7]), u2f(cw[8]), u2f(cw[9]), u2f(cw[10]), u2f(cw[11])};
                 normalize3(vx, vy, vz);
                 float dx = (m[0] * vx + m[1] * vy) + m[2] * vz;
                 float dy = (m[3] * vx + m[4] * vy) + m[5] * vz;
                 float dz = (m[6] * vx + m[7] * vy) + m[8] * vz;
-                float ox = (a.cam.position[0] + 0.0f) * inv_size + 1.0f;
-                float oy = (a.cam.position[1] + 0.0f) * inv_size + 1.0f;
-                float oz = (a.cam.position[2] + 0.0f) * inv_size + 1.0f;
+                float ox = (u2f(cw[0]) + 0.0f) * inv_size + 1.0f;
+                float oy = (u2f(cw[1]) + 0.0f) * inv_size + 1.0f;
+                float oz = (u2f(cw[2]) + 0.0f) * inv_size + 1.0f;
                 Ray r0, r;
                 bool active = ray_setup(r0, root, ox, oy, oz, dx, dy, dz);
                 // every camera ray starts at the camera, on the path of its direction signs
@@ -896,22 +905,28 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
                 uint32_t probe_c0 = 0u, probe_c1 = 0u, probe_c2 = 0u, probe_c3 = 0u;
 #endif
                 if (valid && (NS == 1u || sample < s_end)) {
+                    // the camera block: ONE scalar load of 16 dwords from the kernel-argument segment per sample, live in the ray generation only
+                    typedef uint32_t cam16_t __attribute__((ext_vector_type(16)));
+                    cam16_t cw;
+                    asm volatile("s_load_dwordx16 %0, %1, %2\n s_waitcnt lgkmcnt(0)" : "=s"(cw) : "s"((const void*)ka), "i"((int)__builtin_offsetof(FrameArgs, cam)));
+                    const float cpos0 = u2f(cw[0]), cpos1 = u2f(cw[1]), cpos2 = u2f(cw[2]);
+                    const float cfov = u2f(cw[12]), caperture = u2f(cw[13]), cfocal = u2f(cw[14]);
                     // R0: main.cpp:133,145-149; camera_controller.hpp:34-54
                     // (lens_x / lens_y / the focal point depend on the pixel only, camera_controller.hpp:36-39; hoisting them out of the
                     // sample loop was measured in round 4: 1.254 vs 1.246 ms with frames in flight, 1.336 vs 1.348 alone -- noise)
                     const float aspect_ratio = (float)W / (float)H;
                     const float lens_x = (float)px_x / (float)H - aspect_ratio * 0.5f;
                     const float lens_y = (float)px_y / (float)H - 0.5f;
-                    float sx = lens_x, sy = lens_y, sz = a.cam.fov;
+                    float sx = lens_x, sy = lens_y, sz = cfov;
                     normalize3(sx, sy, sz);
-                    const float fx = sx * a.cam.focal_length, fy = sy * a.cam.focal_length, fz = sz * a.cam.focal_length;
+                    const float fx = sx * cfocal, fy = sy * cfocal, fz = sz * cfocal;
                     float vx = fx, vy = fy, vz = fz;
                     float wx = 0.0f, wy = 0.0f, wz = 0.0f;
-                    const float* m = a.cam.rot;
+                    const float m[9] = {u2f(cw[3]), u2f(cw[4]), u2f(cw[5]), u2f(cw[6]), u2f(cw[7]), u2f(cw[8]), u2f(cw[9]), u2f(cw[10]), u2f(cw[11])};
                     if (!pinhole) {
                         const float r0 = get_rand(counter_rand(a.p.seed, fr, pix, 0u), -0.5f, 0.5f);
                         const float r1 = get_rand(counter_rand(a.p.seed, fr, pix, 1u), -0.5f, 0.5f);
-                        const float rvx = a.cam.aperture * r0, rvy = a.cam.aperture * r1, rvz = a.cam.aperture * 0.0f;
+                        const float rvx = caperture * r0, rvy = caperture * r1, rvz = caperture * 0.0f;
                         vx = fx - rvx; vy = fy - rvy; vz = fz - rvz;
                         wx = (m[0] * rvx + m[1] * rvy) + m[2] * rvz;
                         wy = (m[3] * rvx + m[4] * rvy) + m[5] * rvz;
@@ -921,9 +936,9 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
                     float dx = (m[0] * vx + m[1] * vy) + m[2] * vz;
                     float dy = (m[3] * vx + m[4] * vy) + m[5] * vz;
                     float dz = (m[6] * vx + m[7] * vy) + m[8] * vz;
-                    float ox = (a.cam.position[0] + wx) * inv_size + 1.0f;
-                    float oy = (a.cam.position[1] + wy) * inv_size + 1.0f;
-                    float oz = (a.cam.position[2] + wz) * inv_size + 1.0f;
+                    float ox = (cpos0 + wx) * inv_size + 1.0f;
+                    float oy = (cpos1 + wy) * inv_size + 1.0f;
+                    float oz = (cpos2 + wz) * inv_size + 1.0f;
                     Ray r;
                     bool active = ray_setup(r, root, ox, oy, oz, dx, dy, dz);
                     if constexpr (PINHOLE) {
@@ -939,9 +954,9 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
                         // the iterations saved are lockstep descends, the side selection costs registers the 7-wave build
                         // does not have.  DESIGN.md section 9.)
                         copy_camera_path<VRC_SYNC_ROW>(stk, cam_path, depth, cam_scale);
-                        ray_start_below(r, start_scale_next_to(ox, oy, oz, (a.cam.position[0] + 0.0f) * inv_size + 1.0f,
-                                                               (a.cam.position[1] + 0.0f) * inv_size + 1.0f,
-                                                               (a.cam.position[2] + 0.0f) * inv_size + 1.0f, cam_scale), ox, oy, oz);
+                        ray_start_below(r, start_scale_next_to(ox, oy, oz, (cpos0 + 0.0f) * inv_size + 1.0f,
+                                                               (cpos1 + 0.0f) * inv_size + 1.0f,
+                                                               (cpos2 + 0.0f) * inv_size + 1.0f, cam_scale), ox, oy, oz);
                     }
                     if (a.prim) {                                                   // the capture records the ray's own complexity
                         const uint32_t not_executed = book_not_executed(ctr, active, r);
