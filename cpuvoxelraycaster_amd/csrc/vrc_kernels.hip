@@ -1020,18 +1020,23 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
             acc_r += __shfl_xor(acc_r, 16); acc_g += __shfl_xor(acc_g, 16); acc_b += __shfl_xor(acc_b, 16);
             acc_r += __shfl_xor(acc_r, 32); acc_g += __shfl_xor(acc_g, 32); acc_b += __shfl_xor(acc_b, 32);
         }
+        // The sums' destinations are read from the kernel-argument segment HERE, once per unit, by the 8 x 8 maps' kernels (long
+        // units: the scalar loads' latency does not show, and the pointers' four SGPRs are free during the walks: C3 -0.7 %);
+        // the samples-abreast kernels have four times the units and keep them in registers (measured: +0.8 % with the loads)
+        uint32_t* const unit_accum = NS == 1u ? (uint32_t*)ka->accum : a.accum;
+        uint8_t* const unit_image = NS == 1u ? (uint8_t*)ka->image : a.image;
         const bool writer = valid && sub == 0u;                                      // the lane that owns the pixel's sums
         if (a.p.use_samples && !FUSED) {                                             // raycaster.hpp:87-90
             if (writer) {
                 if (chunks_per_tile == 1u) {
-                    uint4* ap = reinterpret_cast<uint4*>(a.accum) + pix;
+                    uint4* ap = reinterpret_cast<uint4*>(unit_accum) + pix;
                     uint4 v = *ap;
                     v.x += acc_r; v.y += acc_g; v.z += acc_b; v.w += spp;
                     *ap = v;
                 } else {
                     // two 64-bit adds per pixel: (r, g) and (b, count) as pairs of u32 -- a sum never carries out of its
                     // low word (sums < 2^32, as the accumulator format requires), so each half adds independently
-                    unsigned long long* ap = reinterpret_cast<unsigned long long*>(a.accum + 4ull * pix);
+                    unsigned long long* ap = reinterpret_cast<unsigned long long*>(unit_accum + 4ull * pix);
                     atomicAdd(ap + 0, (unsigned long long)acc_r | ((unsigned long long)acc_g << 32));
                     atomicAdd(ap + 1, (unsigned long long)acc_b | ((unsigned long long)(s_end - s_begin) << 32));
                 }
@@ -1044,7 +1049,7 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
             bool resolve = true;
             uint32_t sum_r = acc_r, sum_g = acc_g, sum_b = acc_b, count = s_end - s_begin;
             if (chunks_per_tile != 1u) {
-                unsigned long long* ap = reinterpret_cast<unsigned long long*>(a.accum + 4ull * pix);
+                unsigned long long* ap = reinterpret_cast<unsigned long long*>(unit_accum + 4ull * pix);
                 if (writer) {
                     atomicAdd(ap + 0, (unsigned long long)acc_r | ((unsigned long long)acc_g << 32));
                     atomicAdd(ap + 1, (unsigned long long)acc_b | ((unsigned long long)(s_end - s_begin) << 32));
@@ -1072,7 +1077,7 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
             if (resolve && writer) {
                 uint32_t c = 0xff000000u;
                 if (count) c |= (sum_r / count) | ((sum_g / count) << 8) | ((sum_b / count) << 16);
-                reinterpret_cast<uint32_t*>(a.image)[pix] = c;
+                reinterpret_cast<uint32_t*>(unit_image)[pix] = c;
                 uint32_t* const dst = ka->resolve_dst;
                 if (dst) dst[(uint64_t)compact_row * W + px_x] = c;
             }
@@ -1098,7 +1103,7 @@ __device__ __forceinline__ void render_sync_body(const FrameArgs& a)
         s_pix += __shfl_down(s_pix, off);
     }
     if (lane == 0u) {
-        uint64_t* slot = a.stats + 8u * (blockIdx.x % VRC_STAT_SLOTS);
+        uint64_t* slot = (uint64_t*)ka->stats + 8u * (blockIdx.x % VRC_STAT_SLOTS);      // (once per kernel: not worth two SGPRs until then)
         atomicAdd(reinterpret_cast<unsigned long long*>(slot + 0), ctr[1]);
         atomicAdd(reinterpret_cast<unsigned long long*>(slot + 1), ctr[0] + ctr[VRC_CTR_NOT_EXECUTED]);
         atomicAdd(reinterpret_cast<unsigned long long*>(slot + 2), (unsigned long long)s_hits + ctr[2]);
