@@ -16,7 +16,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=300)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--quad-bias", type=float, default=0.0,
+                    help="probability that a frame case is steered to a launch the quadrant walks apply to (tree of 8+ levels, pinhole camera, "
+                         "sample mode, units of a multiple of four samples, no reuse / checkerboard): the unbiased draw gets there in ~0.1 %% of the frames")
     args = ap.parse_args()
+    import collections
+    kernels = collections.Counter()
     import cpuvoxelraycaster_amd as vrc
     import oracle_lib as O
     import raygen
@@ -49,8 +54,9 @@ def main():
                 print("RAY MISMATCH", it, depth, len(org)); bad += 1
         else:
             # random frame configuration on the terrain, random lane map
+            quad_case = bool(args.quad_bias > 0 and rng.random() < args.quad_bias)     # (no draw at bias 0: old seeds replay)
             if rng.integers(0, 2):
-                depth = int(rng.choice([7, 8, 9]))
+                depth = int(rng.choice([8, 9] if quad_case else [7, 8, 9]))
                 svo = vrc.LSVO.fromFastNoiseTerrain(depth, textures=(top, side))
             else:
                 # random blobs / slabs / noise volume: frames through arbitrary geometry, camera anywhere
@@ -65,20 +71,28 @@ def main():
                 vol |= (rng.random((S0, S0, S0)) < 0.01).astype(np.uint8)
                 if rng.integers(0, 2):
                     vol[:, int(rng.integers(0, S0)), :] = 1
+                if quad_case:
+                    # the same geometry somewhere in the middle of a 256^3 cube: a tree of 8 levels
+                    big = np.zeros((256, 256, 256), np.uint8)
+                    o = [int(rng.integers(max(0, 128 - S0), min(256 - S0, 128) + 1)) for _ in range(3)]
+                    big[o[0]:o[0] + S0, o[1]:o[1] + S0, o[2]:o[2] + S0] = vol
+                    vol, depth = big, 8
                 svo = vrc.LSVO.fromVolume(vol, depth, textures=(top, side))
             nodes = svo.downloadNodes()
             W, H = int(rng.integers(1, 200)), int(rng.integers(1, 120))
-            vrc.capi.check(L.vrc_set_sample_chunk(int(rng.integers(0, 9))))     # 0 = automatic ... whole-spp units
+            spp = int(rng.choice([4, 4, 8, 12, 16])) if quad_case else 0
+            chunk = int(rng.choice([4, 8, spp])) if quad_case else int(rng.integers(0, 9))
+            vrc.capi.check(L.vrc_set_sample_chunk(chunk))                       # 0 = automatic ... whole-spp units
             rc = vrc.RayCaster(svo, (W, H))
-            lane_samples = int(rng.choice([0, 1, 4]))                          # the lane <-> (pixel, sample) map (4 applies to spp % 4 == 0)
+            lane_samples = int(rng.choice([0, 1])) if quad_case else int(rng.choice([0, 1, 4]))                          # the lane <-> (pixel, sample) map (4 applies to spp % 4 == 0)
             rc.setLaneSamples(lane_samples)
             # a quarter of the cases with the invariant-ray reuse (pinhole camera + stage-synchronous kernel: fewer walks
             # executed, same frame; anything else: no effect at all)
-            reuse = bool(rng.integers(0, 4) == 0)
+            reuse = bool(rng.integers(0, 4) == 0) and not quad_case
             rc.setInvariantRayReuse(reuse)
             # the quadrant walks of the pinhole kernels (on by default where a launch allows it: trees of 8+ levels, units of a
             # multiple of four samples): a third of the cases with the plain layout instead
-            if rng.integers(0, 3) == 0:
+            if rng.integers(0, 3) == 0 and not quad_case:
                 rc.setQuadWalks(False)
             # the 6 / 7 / 8 waves-per-SIMD builds of the stage-synchronous kernel (0 = the library's choice)
             blocks = int(rng.choice([0, 0, 6, 7, 8]))
@@ -87,14 +101,14 @@ def main():
             S = float(1 << depth)
             light = vrc.reference_light(depth)
             rc.setLightPosition(light)
-            use_samples = int(rng.integers(0, 2))
+            use_samples = 1 if quad_case else int(rng.integers(0, 2))
             rc.use_gi, rc.use_samples = bool(rng.integers(0, 2)), bool(use_samples)
             rc.shadow_samples = int(rng.choice([0, 1, 2]))
             rc.gi_bounces = int(rng.choice([1, 1, 2]))
             rc.seed = int(rng.integers(1 << 31))
             pos = (S / 2 + rng.uniform(-S / 8, S / 8), S / 2 - rng.uniform(56, 56 + S / 8), S / 2 + rng.uniform(-S / 8, S / 8))
             cam = vrc.make_camera(pos, vrc.make_rotation(float(rng.uniform(-3, 3)), float(rng.uniform(-1.3, 0.3))),
-                                  fov=float(rng.uniform(0.5, 1.5)), aperture=float(rng.choice([0.0, 0.3, 2.0])),
+                                  fov=float(rng.uniform(0.5, 1.5)), aperture=0.0 if quad_case else float(rng.choice([0.0, 0.3, 2.0])),
                                   focal_length=float(rng.uniform(1, 120)))
             # the light of main.cpp:124 most of the time; sometimes anywhere -- inside the cube, far away, on a voxel
             # boundary -- so that the shadow / GI-shadow directions and their normalisation leave the usual range
@@ -107,9 +121,10 @@ def main():
                 light = (np.round(rng.uniform(1.0, 2.0, 3) * S) / S).astype(np.float32)
             if lk <= 2:
                 rc.setLightPosition(light)
-            spp = int(rng.choice([1, 2, 3, 4, 4, 4, 5, 6, 8, 8, 12]))
+            if not quad_case:
+                spp = int(rng.choice([1, 2, 3, 4, 4, 4, 5, 6, 8, 8, 12]))
             nfr = int(rng.integers(1, 3))
-            checker = bool(rng.integers(0, 2))
+            checker = bool(rng.integers(0, 2)) and not quad_case
             # a third of the frames are one rank's shard of a multi-GPU frame
             shard_count = int(rng.choice([1, 1, 2, 3, 5]))
             shard_index = int(rng.integers(0, shard_count))
@@ -139,6 +154,7 @@ def main():
                     mine = oacc[..., 3] > 0                                 # this shard's pixels
                     ok = ok and np.array_equal(rc.readImage()[mine], O.samples_to_image(oacc)[mine]) and not rc.readAccum().any()
             st = rc.stats()
+            kernels[rc.lastKernel()] += 1
             if reuse and cam.aperture == 0.0:
                 ok = ok and st.rays <= rr and st.sum_complexity <= ss
             else:
@@ -151,6 +167,7 @@ def main():
                 print("FRAME MISMATCH", it, dict(depth=depth, W=W, H=H, lane_samples=lane_samples, kernel=rc.lastKernel(), spp=spp, gi=rc.use_gi, samples=use_samples,
                                                  checker=checker, fused=fused, reuse=reuse, blocks=blocks, shard=(row_block, shard_index, shard_count))); bad += 1
             vrc.capi.check(L.vrc_set_sample_chunk(0))
+    print("frame kernels of the last launch of each frame case:", dict(sorted(kernels.items())))
     print(f"fuzz: {it} cases ({frames} frames), {rays_total} rays compared, {bad} mismatches, {time.time() - t0:.0f} s")
     sys.exit(1 if bad else 0)
 
