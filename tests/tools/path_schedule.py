@@ -20,6 +20,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 H_, D_, A_, P_ = 13.0, 25.0, 15.0, 22.0
+MASKS = None     # --dump-masks: [(block, lanes in EXEC)] in issue order, of the shipped policy
+MASK_MULT = 1
 
 
 def highbit(x):
@@ -90,14 +92,20 @@ def simulate(ops, length, policy, lod, start=None):
             cur = ops[np.arange(n), np.minimum(pos, ops.shape[1] - 1)]
             cost += h_cost
             blocks[0] += 1
+            if MASKS is not None and k == 1 and thr == 1:
+                MASKS.append((0, int(active.sum()) * MASK_MULT))
             d = active & (cur == 0)
             a = active & ((cur == 1) | (cur == 2))
             if d.any():
                 cost += D_
                 blocks[1] += 1
+                if MASKS is not None and k == 1 and thr == 1:
+                    MASKS.append((1, int(d.sum()) * MASK_MULT))
             if a.any():
                 cost += A_
                 blocks[2] += 1
+                if MASKS is not None and k == 1 and thr == 1:
+                    MASKS.append((2, int(a.sum()) * MASK_MULT))
             need_pop = active & (cur == 2)
             waiting_pop |= need_pop
             pos[active & ~need_pop] += 1        # descend / plain advance / exit complete this round
@@ -113,6 +121,8 @@ def simulate(ops, length, policy, lod, start=None):
         if run_pop:
             cost += P_
             blocks[3] += 1
+            if MASKS is not None and k == 1 and thr == 1:
+                MASKS.append((3, int(waiting_pop.sum()) * MASK_MULT))
             pos[waiting_pop] += 1
             waiting_pop[:] = False
     policy["_blocks"] = policy.get("_blocks", np.zeros(4, np.int64)) + blocks
@@ -129,7 +139,13 @@ def main():
     ap.add_argument("--quad", action="store_true",
                     help="the pinhole kernel's quadrant walks (round 5): the primary and the shadow stage are walked one 4 x 4 quadrant of "
                          "the tile at a time, each pixel's ray in four lanes (per tile-sample: four walks of 16 distinct rays instead of one of 64)")
+    ap.add_argument("--dump-masks", default="",
+                    help="write the sequence of (block, lanes in EXEC) the shipped policy issues, uint32 = block << 8 | lanes, in issue order "
+                         "(a unit's four GI / GI-shadow walks per four quadrant walks); tools/micro/mask_replay.hip replays it")
     a = ap.parse_args()
+    global MASKS, MASK_MULT
+    if a.dump_masks:
+        MASKS = []
     import cpuvoxelraycaster_amd as vrc
     import oracle_lib as O
     depth, W, Hh = 9, 1920, 1080
@@ -200,7 +216,11 @@ def main():
             for k, pol in policies.items():
                 pol.pop("_blocks", None)
                 for g in groups:
+                    MASK_MULT = 64 // len(g)
+                    n0 = len(MASKS) if (MASKS is not None and k == shipped) else 0
                     c, r = simulate(o[g], ln[g], pol, lod=st >= 2, start=sk[g])
+                    if MASKS is not None and k == shipped and a.quad and len(g) == 64:
+                        MASKS.extend(MASKS[n0:] * 3)
                     tot[k][st] += c / len(groups)
                     rounds[k][st] += r / len(groups)
                 if k == shipped:
@@ -219,6 +239,15 @@ def main():
                        "block is issued when any of the wave's 64 lanes needs it; from the oracle's per-iteration op traces "
                        "(tests/tools/path_schedule.py --dump)"}
         json.dump(doc, open(a.dump, "w"), indent=1)
+    if a.dump_masks:
+        seq = np.array([(b << 8) | min(n, 64) for b, n in MASKS], np.uint32)
+        seq.tofile(a.dump_masks)
+        cls = np.array([14, 24, 16, 21])[seq >> 8]
+        print(f"{len(seq)} block issues written to {a.dump_masks}; with <= 8 lanes in EXEC: {np.mean((seq & 255) <= 8) * 100:.1f} % of the issues, "
+              f"{(cls * ((seq & 255) <= 8)).sum() / cls.sum() * 100:.1f} % of the loop's VALU instructions")
+        for i, nm in enumerate(("header", "descend", "advance", "pop")):
+            m = (seq >> 8) == i
+            print(f"  {nm:8s} {m.mean() * 100:5.1f} % of the issues, mean {(seq[m] & 255).mean():5.1f} lanes, <= 8 lanes in {np.mean((seq[m] & 255) <= 8) * 100:5.1f} %")
     base = tot["now (pop whenever a lane needs it)"]
     print(f"{len(tiles)} tiles; issued VALU instructions per tile-sample and stage (rounds in brackets)")
     for k in policies:
