@@ -129,6 +129,42 @@ def simulate(ops, length, policy, lod, start=None):
     return cost, rnd
 
 
+def simulate_work_list(ops, length, T, lod, start=None):
+    """A work list inside the wave (round 5): lanes wait in the set of the block they need next (descend / advance / pop) and a
+    round issues the header for the lanes that need none, then every pending set with >= T lanes and always the fullest one.
+    T = 1 is the shipped loop.  Returns issued VALU instructions, rounds."""
+    n = len(length)
+    pos = np.zeros(n, np.int64) if start is None else np.minimum(start.astype(np.int64), length)
+    pend = np.zeros(n, np.int8)                 # 0 none, 1 descend, 2 advance, 3 advance then pop, 4 pop
+    cost, rounds = 0.0, 0
+    h_cost = H_ + (2.0 if lod else 0.0)
+    lane = np.arange(n)
+    while True:
+        alive = pos < length
+        if not alive.any():
+            return cost, rounds
+        rounds += 1
+        fresh = alive & (pend == 0)
+        if fresh.any():
+            cur = ops[lane, np.minimum(pos, ops.shape[1] - 1)]
+            cost += h_cost
+            pend[fresh & (cur == 0)] = 1
+            pend[fresh & (cur == 1)] = 2
+            pend[fresh & (cur == 2)] = 3
+            pos[fresh & (cur > 2)] += 1         # an exit the header decides
+        cnt = {1: int((alive & (pend == 1)).sum()), 2: int((alive & ((pend == 2) | (pend == 3))).sum()), 4: int((alive & (pend == 4)).sum())}
+        big = max(cnt, key=lambda k: cnt[k])
+        for kind in (1, 2, 4):
+            if cnt[kind] and (cnt[kind] >= T or kind == big):
+                if kind == 1:
+                    m = alive & (pend == 1); cost += D_; pos[m] += 1; pend[m] = 0
+                elif kind == 2:
+                    m2, m3 = alive & (pend == 2), alive & (pend == 3)
+                    cost += A_; pos[m2] += 1; pend[m2] = 0; pend[m3] = 4
+                else:
+                    m = alive & (pend == 4); cost += P_; pos[m] += 1; pend[m] = 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--band", type=int, default=32, help="render 1 / band of the 8-row blocks")
@@ -139,6 +175,9 @@ def main():
     ap.add_argument("--quad", action="store_true",
                     help="the pinhole kernel's quadrant walks (round 5): the primary and the shadow stage are walked one 4 x 4 quadrant of "
                          "the tile at a time, each pixel's ray in four lanes (per tile-sample: four walks of 16 distinct rays instead of one of 64)")
+    ap.add_argument("--work-list", action="store_true",
+                    help="also price a work list inside the wave: lanes wait in the set of the block they need next, a round issues the "
+                         "sets with >= T lanes and always the fullest (simulate_work_list)")
     ap.add_argument("--dump-masks", default="",
                     help="write the sequence of (block, lanes in EXEC) the shipped policy issues, uint32 = block << 8 | lanes, in issue order "
                          "(a unit's four GI / GI-shadow walks per four quadrant walks); tools/micro/mask_replay.hip replays it")
@@ -191,6 +230,7 @@ def main():
                 "pop when >= 8 lanes wait": {"pop_threshold": 8}, "pop when >= 16 lanes wait": {"pop_threshold": 16},
                 "pop when >= 24 lanes wait": {"pop_threshold": 24}, "pop when >= 32 lanes wait": {"pop_threshold": 32}}
     names = ["primary", "shadow", "GI", "GI shadow"]
+    WL = {T: (np.zeros(4), np.zeros(4)) for T in (1, 4, 8, 12, 16, 24, 32)}
     tot = {k: np.zeros(4) for k in policies}
     rounds = {k: np.zeros(4) for k in policies}
     shipped = "now (pop whenever a lane needs it)"
@@ -213,6 +253,12 @@ def main():
                 groups = [np.arange(64)]
             # (a quadrant walk covers 16 pixels x 4 samples = one tile-sample's worth of rays: per tile-sample the stage costs the
             # MEAN of the four quadrants' walks)
+            if a.work_list:
+                for T in WL:
+                    for g in groups:
+                        c, r = simulate_work_list(o[g], ln[g], T, st >= 2, sk[g])
+                        WL[T][0][st] += c / len(groups)
+                        WL[T][1][st] += r / len(groups)
             for k, pol in policies.items():
                 pol.pop("_blocks", None)
                 for g in groups:
@@ -253,6 +299,10 @@ def main():
     for k in policies:
         line = "  ".join(f"{names[i]} {tot[k][i] / len(tiles):7.0f} [{rounds[k][i] / len(tiles):5.1f}]" for i in range(4))
         print(f"{k:36s} {line}   total {tot[k].sum() / len(tiles):7.0f} ({(tot[k].sum() / base.sum() - 1) * 100:+5.1f} %)")
+    if a.work_list:
+        for T, (c, r) in WL.items():
+            line = "  ".join(f"{names[i]} {c[i] / len(tiles):7.0f} [{r[i] / len(tiles):5.1f}]" for i in range(4))
+            print(f"{'work list, sets with >= %d lanes' % T:36s} {line}   total {c.sum() / len(tiles):7.0f} ({(c.sum() / WL[1][0].sum() - 1) * 100:+5.1f} %)")
 
 
 if __name__ == "__main__":
