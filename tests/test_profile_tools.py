@@ -93,3 +93,42 @@ def test_issue_model_reads_the_walk_loop_and_is_current():
     assert abs(sum(pts.get(c, 0) for c in "ABSQP") - sum(doc["walks_per_tile_sample"].get(c, 0) for c in "ABSQP")) < 0.1
     f = issue_model.floor_cycles(1000.0, 100.0, 0.0, 400.0)
     assert f["valu_arch"] == 2000.0 and f["slow_unit"] == 430.0 and abs(f["scalar_unit"] - 440.0) < 1e-9
+
+
+def test_path_schedule_policies_on_a_synthetic_walk():
+    """tests/tools/path_schedule.py's wave simulations (the shipped loop and round 5's work list of pending blocks) on a walk
+    whose answer is known: lanes that all take the same path issue each block once per round whatever the policy, and a
+    divergent wave never issues fewer blocks than its fullest lane needs."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+    import path_schedule as ps
+    n, L = 64, 12
+    # op codes per iteration: 0 descend, 1 advance, 2 advance + pop; the same for every lane
+    row = np.array([0, 0, 1, 2, 0, 1, 2, 2, 1, 0, 1, 2], np.uint8)
+    ops = np.tile(row, (n, 1))
+    length = np.full(n, L, np.int64)
+    cost, rounds = ps.simulate(ops, length, {}, lod=False)
+    want = L * ps.H_ + (row == 0).sum() * ps.D_ + (row != 0).sum() * ps.A_ + (row == 2).sum() * ps.P_
+    assert (cost, rounds) == (want, L)
+    c2, r2 = ps.simulate_work_list(ops, length, 1, lod=False)
+    assert c2 == want                      # one path per round: nothing waits for anything (the pops run a round late)
+    assert r2 >= rounds
+    # a divergent wave: every policy executes every lane's iterations, and costs at least the uniform wave's blocks
+    rng = np.random.default_rng(1)
+    ops = rng.integers(0, 3, (n, L)).astype(np.uint8)
+    length = rng.integers(1, L + 1, n).astype(np.int64)
+    base, _ = ps.simulate(ops, length, {}, lod=True)
+    for T in (1, 8, 32):
+        c, r = ps.simulate_work_list(ops, length, T, lod=True)
+        assert c > 0 and r >= int(length.max())
+    assert base >= int(length.max()) * (ps.H_ + 2.0)
+    # the mask dump records one entry per issued block, in issue order, with the lanes that executed it
+    ps.MASKS = []
+    try:
+        ps.simulate(ops, length, {}, lod=True)
+        blocks = np.array([b for b, _ in ps.MASKS])
+        lanes = np.array([k for _, k in ps.MASKS])
+        assert (blocks == 0).sum() == int(length.max()) and lanes.min() >= 1 and lanes.max() <= n
+        assert lanes[blocks == 0].sum() == int(length.sum())          # every lane-iteration went through one header
+    finally:
+        ps.MASKS = None
