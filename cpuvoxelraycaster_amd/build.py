@@ -19,6 +19,12 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
          "-fno-fast-math", "-fno-slp-vectorize", "-Wall", "-Wno-unused-result"]
 
 
+# The experiment switches of the sources (VRC_EXTRA_FLAGS / tools/build_variant.py / tools/probe_waves.py); never part of the
+# product's flag line.  tests/test_variant_builds.py holds every one of them to a compiler front-end pass (host and device).
+VARIANT_FLAGS = ["-DVRC_PROBE", "-DVRC_WALK_CPP", "-DVRC_NO_START_BELOW", "-DVRC_NO_PINHOLE_KERNEL", "-DVRC_WALK_LATE_WAIT",
+                 "-DVRC_WALK_GLOBAL_LOAD", "-DVRC_EXP_UNITS", "-DVRC_SYNC_Q_WAVES=7", "-DVRC_SYNC_MIN_WAVES=5"]
+
+
 STAMP = LIB + ".flags"   # the flags the library was built with: an experiment build is never mistaken for the product
 
 

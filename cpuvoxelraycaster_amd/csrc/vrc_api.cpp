@@ -639,88 +639,92 @@ int render_impl(vrc_renderer* r, const vrc_camera* cam, const vrc_frame_params* 
     a.walk_from_root = tuning.walk_from_root ? 1u : 0u;
     a.tile_done = r->d_tile_done;
     a.resolve_dst = (uint32_t*)dst;
-    uint64_t want = (items + VRC_RENDER_BLOCK - 1) / VRC_RENDER_BLOCK;
-    uint32_t bpc = 0;
-    {
-        const uint32_t lds = 2u * s->depth * 1024u + 1536u + 128u + 544u + 32u;  // two stacks (primary path, secondary walks), tables, counters, camera paths
-        const uint32_t fit = 163840u / lds;
-        // which build of the kernel (waves per SIMD = workgroups per CU): by the kind of launch, or the caller's choice
-        const bool whole_spp = a.p.use_samples && a.p.spp > 1 && tuning.sample_chunk >= a.p.spp;
-        uint32_t waves = vrc::sync_waves_for(vrc::camera_is_pinhole(a.cam), a.p.gi_bounces <= 1, a.p.use_gi != 0, whole_spp,
-                                             (uint64_t)a.n_items * a.p.spp, tuning.blocks_per_cu_set ? tuning.blocks_per_cu : 0u);
-        if (a.lane_samples == 4u) waves = vrc::sync_s4_waves(vrc::camera_is_pinhole(a.cam));
-        if (waves > fit) waves = vrc::sync_max_blocks_per_cu();          // deep trees: the stacks of 8 workgroups do not fit a CU's LDS
-        a.waves = waves;
-        bpc = waves;
-        if (tuning.blocks_per_cu_set && tuning.blocks_per_cu < bpc) bpc = tuning.blocks_per_cu;
-        if (bpc > fit) bpc = fit;
-    }
-    const uint64_t cap = (uint64_t)s->cu_count * bpc;
-    a.sample_chunk = 0;
-    if (a.p.use_samples && a.p.spp > 1) {
-        // Units should be short against the launch (its end waits for the last unit of every wave, and the oldest
-        // wave of a SIMD runs ~3.6x faster than the youngest) yet not so small that the accumulator atomics and
-        // queue traffic show: the largest chunk that still gives ~48 units per wave of a full grid, else 2 samples
-        // per unit, else (small multi-GPU shards) 1.  Measured: C3 1.91 -> 1.83 ms, C5 26.3 -> 26.0 ms
-        // (tools/chunk_time.py).
-        const uint64_t tiles = a.n_items / 64, waves = cap * (VRC_RENDER_BLOCK / 64);
-        uint32_t c = tuning.sample_chunk ? tuning.sample_chunk : a.p.spp;
-        if (c > a.p.spp) c = a.p.spp;
-        if (!tuning.sample_chunk && a.lane_samples == 4u) {
-            // four samples abreast: a unit's samples come in fours (a tile has 16 pixels, so there are four times the units)
-            while (c % 8u == 0u && tiles * (a.p.spp / c) < 48 * waves) c /= 2;
-        } else if (!tuning.sample_chunk) {
-            while (c > 2 && tiles * ((a.p.spp + c - 1) / c) < 48 * waves) c = (c + 1) / 2;
-            if (c == 2 && tiles * ((a.p.spp + 1) / 2) < 8 * waves) c = 1;
-        }
-        a.sample_chunk = c < a.p.spp ? c : 0;
-        // shorter units for the tiles handed out last (about four per wave): halves the spread of the waves' end times
-        uint64_t units = tiles * ((a.p.spp + c - 1) / c);
-        if (!tuning.sample_chunk && c >= 2 && tuning.tail_units_per_wave && (a.lane_samples == 1u || c % 8u == 0u)) {
-            const uint32_t ct = c / 2, cpt_tail = (a.p.spp + ct - 1) / ct;
-            uint64_t tt = (uint64_t)tuning.tail_units_per_wave * waves / cpt_tail;
-            if (tt > tiles) tt = tiles;
-            a.sample_chunk_tail = ct;
-            a.tail_tiles = (uint32_t)tt;
-            units = (tiles - tt) * ((a.p.spp + c - 1) / c) + tt * cpt_tail;
-        }
-#ifdef VRC_EXP_UNITS   // experiment builds only (tools/build_variant.py): "head chunk,tail chunk,tail units per wave" from the environment
-        if (const char* ev = getenv("VRC_EXP_UNITS")) {
-            unsigned ec = 0, ect = 0, etpw = 0;
-            if (sscanf(ev, "%u,%u,%u", &ec, &ect, &etpw) == 3 && ec >= 1 && ect >= 1 && a.lane_samples == 1u) {
-                c = ec > a.p.spp ? a.p.spp : ec;
-                a.sample_chunk = c < a.p.spp ? c : 0;
-                const uint32_t cpt_tail = (a.p.spp + ect - 1) / ect;
-                uint64_t tt = (uint64_t)etpw * waves / cpt_tail;
-                if (tt > tiles) tt = tiles;
-                a.sample_chunk_tail = ect; a.tail_tiles = (uint32_t)tt;
-                units = (tiles - tt) * ((a.p.spp + c - 1) / c) + tt * cpt_tail;
-            }
-        }
-#endif
-        // the kernel numbers work units in 32 bits
-        if (units > 0xfffffff0ull) return fail(VRC_ERR_INVALID, "vrc_render_frame: %llu work units (tiles x sample chunks) do not fit 32 bits; "
-                                               "use fewer samples per call or a larger sample chunk", (unsigned long long)units);
-        // one wave per unit until the chip is full: a shard of few tiles still spreads over all CUs
-        want = (units + VRC_RENDER_BLOCK / 64 - 1) / (VRC_RENDER_BLOCK / 64);
-    }
     // Quadrant walks (render_sync_body's QUAD; vrc_renderer_set_quad_walks, on by default): the pinhole kernels on the 8 x 8 map
     // when every work unit has a multiple of four samples (the walks of a pixel's sample-invariant rays are laid out four
     // abreast), without invariant-ray reuse (one walk per unit: nothing to lay out) and without the primary-hit capture (which
     // records per-lane complexities); the tree must have 8 levels or more (a walk's final state waits in stack rows 3..7).
-    uint64_t cap_launch = cap;
-    {
-        const uint32_t c_head = a.sample_chunk ? a.sample_chunk : a.p.spp, c_tail = a.sample_chunk_tail ? a.sample_chunk_tail : c_head;
-        if (tuning.quad_walks && a.lane_samples == 1u && a.p.use_samples && a.p.spp % 4u == 0u && c_head % 4u == 0u && c_tail % 4u == 0u &&
-            !a.reuse_invariant && !a.prim && !a.walk_from_root && !a.checker_wide && vrc::camera_is_pinhole(a.cam) && s->depth >= 8u) {
-            a.quad_walks = 1u;
-            // (its builds sit at their own occupancy, whatever the plain kernel of this launch would have had)
-            const uint32_t fitq = 163840u / (2u * s->depth * 1024u + 1536u + 128u + 544u + 32u + vrc::quad_lds_bytes());
-            uint32_t bq = vrc::quad_waves() < fitq ? vrc::quad_waves() : fitq;
-            if (tuning.blocks_per_cu_set && tuning.blocks_per_cu < bq) bq = tuning.blocks_per_cu;
-            cap_launch = (uint64_t)s->cu_count * bq;
+    // Decided BEFORE the occupancy and the unit policy, which follow the build that is launched (its builds sit at their own
+    // occupancy); the one condition that needs the policy's result -- every unit a multiple of four samples -- is checked after
+    // it, and a launch that fails it is planned again for the plain build.
+    const bool quad_candidate = vrc::quad_available() && tuning.quad_walks && a.lane_samples == 1u && a.p.use_samples && a.p.spp % 4u == 0u &&
+                                !a.reuse_invariant && !a.prim && !a.walk_from_root && !a.checker_wide && vrc::camera_is_pinhole(a.cam) && s->depth >= 8u;
+    uint64_t want = 0, cap = 0;
+    auto plan = [&](bool quad) -> int {
+        want = (items + VRC_RENDER_BLOCK - 1) / VRC_RENDER_BLOCK;
+        a.sample_chunk = a.sample_chunk_tail = a.tail_tiles = 0;
+        uint32_t bpc = 0;
+        {
+            const uint32_t lds = 2u * s->depth * 1024u + 1536u + 128u + 544u + 32u + (quad ? vrc::quad_lds_bytes() : 0u);  // two stacks (primary path, secondary walks), tables, counters, camera paths
+            const uint32_t fit = 163840u / lds;
+            // which build of the kernel (waves per SIMD = workgroups per CU): by the kind of launch, or the caller's choice
+            const bool whole_spp = a.p.use_samples && a.p.spp > 1 && tuning.sample_chunk >= a.p.spp;
+            uint32_t waves = vrc::sync_waves_for(vrc::camera_is_pinhole(a.cam), a.p.gi_bounces <= 1, a.p.use_gi != 0, whole_spp,
+                                                 (uint64_t)a.n_items * a.p.spp, tuning.blocks_per_cu_set ? tuning.blocks_per_cu : 0u);
+            if (a.lane_samples == 4u) waves = vrc::sync_s4_waves(vrc::camera_is_pinhole(a.cam));
+            if (quad) waves = vrc::quad_waves();
+            if (waves > fit) waves = quad ? fit : vrc::sync_max_blocks_per_cu();   // deep trees: the stacks of 8 workgroups do not fit a CU's LDS
+            a.waves = waves;
+            bpc = waves;
+            if (tuning.blocks_per_cu_set && tuning.blocks_per_cu < bpc) bpc = tuning.blocks_per_cu;
+            if (bpc > fit) bpc = fit;
         }
+        cap = (uint64_t)s->cu_count * bpc;
+        if (a.p.use_samples && a.p.spp > 1) {
+            // Units should be short against the launch (its end waits for the last unit of every wave, and the oldest
+            // wave of a SIMD runs ~3.6x faster than the youngest) yet not so small that the accumulator atomics and
+            // queue traffic show: the largest chunk that still gives ~48 units per wave of a full grid, else 2 samples
+            // per unit, else (small multi-GPU shards) 1.  Measured: C3 1.91 -> 1.83 ms, C5 26.3 -> 26.0 ms
+            // (tools/chunk_time.py).
+            const uint64_t tiles = a.n_items / 64, waves = cap * (VRC_RENDER_BLOCK / 64);
+            uint32_t c = tuning.sample_chunk ? tuning.sample_chunk : a.p.spp;
+            if (c > a.p.spp) c = a.p.spp;
+            if (!tuning.sample_chunk && a.lane_samples == 4u) {
+                // four samples abreast: a unit's samples come in fours (a tile has 16 pixels, so there are four times the units)
+                while (c % 8u == 0u && tiles * (a.p.spp / c) < 48 * waves) c /= 2;
+            } else if (!tuning.sample_chunk) {
+                while (c > 2 && tiles * ((a.p.spp + c - 1) / c) < 48 * waves) c = (c + 1) / 2;
+                if (c == 2 && tiles * ((a.p.spp + 1) / 2) < 8 * waves) c = 1;
+            }
+            a.sample_chunk = c < a.p.spp ? c : 0;
+            // shorter units for the tiles handed out last (about four per wave): halves the spread of the waves' end times
+            uint64_t units = tiles * ((a.p.spp + c - 1) / c);
+            if (!tuning.sample_chunk && c >= 2 && tuning.tail_units_per_wave && (a.lane_samples == 1u || c % 8u == 0u)) {
+                const uint32_t ct = c / 2, cpt_tail = (a.p.spp + ct - 1) / ct;
+                uint64_t tt = (uint64_t)tuning.tail_units_per_wave * waves / cpt_tail;
+                if (tt > tiles) tt = tiles;
+                a.sample_chunk_tail = ct;
+                a.tail_tiles = (uint32_t)tt;
+                units = (tiles - tt) * ((a.p.spp + c - 1) / c) + tt * cpt_tail;
+            }
+#ifdef VRC_EXP_UNITS   // experiment builds only (tools/build_variant.py): "head chunk,tail chunk,tail units per wave" from the environment
+            if (const char* ev = getenv("VRC_EXP_UNITS")) {
+                unsigned ec = 0, ect = 0, etpw = 0;
+                if (sscanf(ev, "%u,%u,%u", &ec, &ect, &etpw) == 3 && ec >= 1 && ect >= 1 && a.lane_samples == 1u) {
+                    c = ec > a.p.spp ? a.p.spp : ec;
+                    a.sample_chunk = c < a.p.spp ? c : 0;
+                    const uint32_t cpt_tail = (a.p.spp + ect - 1) / ect;
+                    uint64_t tt = (uint64_t)etpw * waves / cpt_tail;
+                    if (tt > tiles) tt = tiles;
+                    a.sample_chunk_tail = ect; a.tail_tiles = (uint32_t)tt;
+                    units = (tiles - tt) * ((a.p.spp + c - 1) / c) + tt * cpt_tail;
+                }
+            }
+#endif
+            // the kernel numbers work units in 32 bits
+            if (units > 0xfffffff0ull) return fail(VRC_ERR_INVALID, "vrc_render_frame: %llu work units (tiles x sample chunks) do not fit 32 bits; "
+                                                   "use fewer samples per call or a larger sample chunk", (unsigned long long)units);
+            // one wave per unit until the chip is full: a shard of few tiles still spreads over all CUs
+            want = (units + VRC_RENDER_BLOCK / 64 - 1) / (VRC_RENDER_BLOCK / 64);
+        }
+        return VRC_OK;
+    };
+    if (int rc = plan(quad_candidate)) return rc;
+    if (quad_candidate) {
+        const uint32_t c_head = a.sample_chunk ? a.sample_chunk : a.p.spp, c_tail = a.sample_chunk_tail ? a.sample_chunk_tail : c_head;
+        if (c_head % 4u == 0u && c_tail % 4u == 0u) a.quad_walks = 1u;
+        else if (int rc = plan(false)) return rc;
     }
+    const uint64_t cap_launch = cap;
     const uint32_t grid = (uint32_t)(want < cap_launch ? want : cap_launch);
     HIP_TRY(vrc::launch_render(a, grid, st, &r->last_kernel));
     if (queue_used >= 0) r->queue_zero[1 - queue_used] = true;           // zeroed by the launch that is now in the stream

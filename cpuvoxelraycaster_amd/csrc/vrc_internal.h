@@ -89,6 +89,7 @@ hipError_t launch_grid_cast(const uint8_t* cells, int X, int Y, int Z, uint64_t 
 uint32_t sync_max_blocks_per_cu();    // register-limited workgroups per CU of k_render_sync
 uint32_t quad_lds_bytes();            // LDS a workgroup of the quadrant-walk kernels needs on top
 uint32_t quad_waves();                // waves per SIMD the quadrant-walk kernels are built for
+bool quad_available();                // false in the variant builds that leave the quadrant-walk kernels out (launch_render would fall back)
 uint32_t sync_s4_waves(bool pinhole); // waves per SIMD the samples-abreast builds were compiled for
 // The stage-synchronous kernels are built for 6 waves per SIMD (80 VGPRs), the lens one-bounce kernel also for 7 (72).
 // Rounds 2 and 3 shipped 7- and 8-wave builds of the pinhole kernels too, picked by a table (profiles/r03/sweep_waves.txt:

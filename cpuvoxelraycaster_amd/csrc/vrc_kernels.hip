@@ -1143,11 +1143,12 @@ VRC_SYNC_KERNEL_NS(k_render_sync_resolved_s4, false, true, true, VRC_SYNC_S4_WAV
 VRC_SYNC_KERNEL_NS(k_render_sync_pinhole_s4, true, true, false, VRC_SYNC_S4_WAVES, 4u)
 VRC_SYNC_KERNEL_NS(k_render_sync_pinhole_resolved_s4, true, true, true, VRC_SYNC_S4_WAVES, 4u)
 // the pinhole kernels with quadrant walks (render_sync_body's QUAD)
-#if !(defined(VRC_WALK_CPP) || defined(VRC_PROBE) || defined(VRC_NO_START_BELOW))
-#define VRC_HAVE_QUAD 1
+// (the variant builds -- the C++ walk, the probes, every ray from the root -- have no quadrant-walk kernels: quad_available())
 #ifndef VRC_SYNC_Q_WAVES
 #define VRC_SYNC_Q_WAVES 6
 #endif
+#if !(defined(VRC_WALK_CPP) || defined(VRC_PROBE) || defined(VRC_NO_START_BELOW))
+#define VRC_HAVE_QUAD 1
 #define VRC_SYNC_KERNEL_Q(name, ONE_BOUNCE, FUSED)                                                         \
     extern "C" __global__ void __launch_bounds__(VRC_RENDER_BLOCK, VRC_SYNC_Q_WAVES) name(const FrameArgs a)  \
     {                                                                                                      \
@@ -1369,6 +1370,14 @@ hipError_t launch_grid_cast(const uint8_t* cells, int X, int Y, int Z, uint64_t 
 uint32_t sync_max_blocks_per_cu() { return VRC_SYNC_MIN_WAVES; }
 uint32_t quad_lds_bytes() { return VRC_QUAD_LDS_BYTES; }
 uint32_t quad_waves() { return VRC_SYNC_Q_WAVES; }
+bool quad_available()
+{
+#ifdef VRC_HAVE_QUAD
+    return true;
+#else
+    return false;
+#endif
+}
 uint32_t sync_s4_waves(bool pinhole) { return pinhole ? VRC_SYNC_S4_WAVES : VRC_SYNC_S4_WAVES_LENS; }
 uint32_t sync_waves_for(bool pinhole, bool one_bounce, bool use_gi, bool whole_spp_units, uint64_t pixel_samples, uint32_t requested)
 {

@@ -115,19 +115,31 @@ class PeerFrames:
         self.pids = [e[2] for k, e in enumerate(everyone) if k != rank]      # the peers this rank's streams may wait for
         everyone = [e[0] for e in everyone]
         self.targets = []
+        # A rank that cannot map the segment or a framebuffer (IPC mode mismatch, handle refused) must not leave the others in a
+        # barrier until the process-group timeout: every rank reports how its set-up went, and every rank raises the first
+        # failure by name (round-5 advice).  The name is unlinked only when all of them have the segment mapped.
+        problem = None
         if rank != 0:
-            capi.check(L.vrc_ipc_flags_open(name.encode(), n, device, 0, C.byref(self._flags)))
-            for s, r in enumerate(renderers):
-                buf = (C.c_ubyte * 64).from_buffer_copy(everyone[0][s])
-                tgt = C.c_void_p()
-                capi.check(L.vrc_ipc_open_image(device, C.byref(buf), C.byref(tgt)))
-                self.targets.append(tgt)
-                r.setImageTarget(tgt)
-        # every rank has the segment mapped now: its name can go (the mappings stay valid), so that a run that is killed
-        # later -- launch_ranks ends stragglers by SIGKILL -- leaves nothing behind in /dev/shm
-        dist.barrier(group=group)
+            try:
+                capi.check(L.vrc_ipc_flags_open(name.encode(), n, device, 0, C.byref(self._flags)))
+                for s, r in enumerate(renderers):
+                    buf = (C.c_ubyte * 64).from_buffer_copy(everyone[0][s])
+                    tgt = C.c_void_p()
+                    capi.check(L.vrc_ipc_open_image(device, C.byref(buf), C.byref(tgt)))
+                    self.targets.append(tgt)
+                    r.setImageTarget(tgt)
+            except Exception as e:                              # noqa: BLE001  (reported below, on every rank)
+                problem = f"rank {rank}: {e}"
+        outcome = [None] * world
+        dist.all_gather_object(outcome, problem, group=group)
+        # every rank has the segment mapped now (or has said why not): its name can go (the mappings stay valid), so that a run
+        # that is killed later -- launch_ranks ends stragglers by SIGKILL -- leaves nothing behind in /dev/shm
         if rank == 0:
             capi.check(L.vrc_ipc_flags_unlink(self._flags))
+        failed = [o for o in outcome if o]
+        if failed:
+            self.close()
+            raise capi.VrcError("direct peer writes could not be set up: " + "; ".join(failed))
 
     def _written(self, slot, k):
         return slot * self.world + k

@@ -43,7 +43,14 @@ def main():
     rcs = [make() for _ in range(in_flight)]
     streams = [torch.cuda.Stream() for _ in range(in_flight)]
     dbg("renderers made")
-    peers = vd.PeerFrames(rcs, 0, rank, world, dist.group.WORLD, "/vrc_peer_test_%s" % os.environ["MASTER_PORT"])
+    if rank == int(os.environ.get("PW_BAD_SETUP_RANK", "-1")):
+        # the set-up failure test: this rank cannot open rank 0's framebuffer (what an IPC mode mismatch looks like)
+        vrc.capi.load().vrc_ipc_open_image = lambda *a: vrc.capi.load().vrc_ipc_close_image(-1, 1)   # an error code + vrc_last_error
+    try:
+        peers = vd.PeerFrames(rcs, 0, rank, world, dist.group.WORLD, "/vrc_peer_test_%s" % os.environ["MASTER_PORT"])
+    except vrc.capi.VrcError as e:
+        print(json.dumps({"rank": rank, "error": str(e)}), flush=True)
+        os._exit(8)
     dbg("peer frames set up")
 
     class _Alias:                       # a renderer's framebuffer as a torch tensor (no copy)

@@ -137,3 +137,33 @@ def test_cpp_host_dead_writer(built, tmp_path):
         os.killpg(p.pid, 9)
         raise AssertionError("peer_write_main hung on the dead writer's flag")
     assert p.returncode == 6 and "vrc_ipc_stream_wait" in err, (p.returncode, err[-800:])
+
+
+def test_a_rank_that_cannot_map_the_framebuffers_fails_every_rank_at_once(built):
+    """round-5 advice: PeerFrames' set-up had a barrier behind the hipIpc opens, so a rank whose open failed (an IPC mode
+    mismatch) left the others waiting for the process-group timeout and the run reported the hang, not the cause.  Now every
+    rank reports its set-up and every rank raises the first failure by name: all three leave with the worker's exit code 8
+    within seconds, and the message names the rank and the reason."""
+    import time
+    port = _free_port()
+    procs = []
+    t0 = time.monotonic()
+    for rank in range(3):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="3", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   PW_BAD_SETUP_RANK="2")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "peer_write_worker.py")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=90)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise AssertionError("the other ranks hung on the rank whose set-up failed")
+        outs.append((p.returncode, o, e))
+    assert [rc for rc, _, _ in outs] == [8, 8, 8], [(rc, e[-500:]) for rc, _, e in outs]
+    for rc, o, _ in outs:
+        d = json.loads([ln for ln in o.splitlines() if ln.startswith("{")][-1])
+        assert "could not be set up" in d["error"] and "rank 2" in d["error"] and "out of range" in d["error"], d
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("vrc_peer_test_%d" % port)]      # the segment's name is gone

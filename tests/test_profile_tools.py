@@ -83,6 +83,15 @@ def test_issue_model_reads_the_walk_loop_and_is_current():
     assert valu(nolod["start"]) == 11 and nolod["start"]["lds"] == 1 and nolod["start"]["vmem"] == 1   # entry of a ray that starts below the root
     assert all(b.get("P", 0) == 0 for b in nolod.values())               # no packed / lane-access instruction in the loop
     assert nolod["descend"]["lds"] == 1 and nolod["pop"]["lds"] == 1 and nolod["descend"]["vmem"] == 1 and nolod["pop"]["vmem"] == 1
+    # the header is read in the SHIPPED variant (the product defines none of the A/B switches): the wait for the node comes
+    # before the exits' compare class, and the text with VRC_WALK_LATE_WAIT defined is the other one (round-5 advice)
+    assert list(nolod["header"]).index("wait") < list(nolod["header"]).index("Q")
+    src = open(issue_model.WALK).read()
+    shipped = issue_model.macro_body(issue_model.preprocess(src), "VRC_WALK_HEADER_REST")
+    late = issue_model.macro_body(issue_model.preprocess(src, defined=("VRC_WALK_LATE_WAIT",)), "VRC_WALK_HEADER_REST")
+    first = lambda body: body.lstrip("\\ \n\t")
+    assert first(shipped).startswith('"s_waitcnt') and first(late).startswith('"v_sub_f32') and "s_waitcnt" in late
+    assert "buffer_load" in issue_model.macro_body(issue_model.preprocess(src), "VRC_WALK_LOAD_NODE")
     lane = issue_model.block_counts(0, True)                             # per-lane complexity: one VALU more, two scalar fewer
     assert valu(lane["header"]) == 15 and lane["header"]["salu"] == nolod["header"]["salu"] - 2
     doc = json.load(open(os.path.join(ROOT, "profiles", "issue_model.json")))

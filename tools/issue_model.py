@@ -74,6 +74,26 @@ def classify(op):
     return "Q"
 
 
+def preprocess(src, defined=()):
+    """the lines the compiler sees for the product's flags: #ifdef / #ifndef / #else / #endif resolved against `defined` (the
+    product build defines none of the A/B switches), so that a macro with two variants is read in the shipped one whatever
+    their order in the file (round-5 advice)"""
+    out, stack = [], []                # stack of (taking this branch, any enclosing branch skipped)
+    for line in src.split("\n"):
+        m = re.match(r"\s*#\s*(ifdef|ifndef|else|endif)\b\s*(\w+)?", line)
+        if m and m.group(1) in ("ifdef", "ifndef"):
+            take = (m.group(2) in defined) == (m.group(1) == "ifdef")
+            stack.append(take)
+        elif m and m.group(1) == "else":
+            stack[-1] = not stack[-1]
+        elif m and m.group(1) == "endif":
+            stack.pop()
+        elif all(stack):
+            out.append(line)
+    assert not stack, "unbalanced #if in the walk header"
+    return "\n".join(out)
+
+
 def macro_body(src, name):
     """text of a (possibly function-like) #define, continuation lines joined"""
     m = re.search(r"^#define\s+" + re.escape(name) + r"(\([^)]*\))?[ \t]+(.*?)(?<!\\)\n", src, re.S | re.M)
@@ -100,8 +120,6 @@ def expand(src, lod_mode, count_lane):
            "TMAXPART": "VRC_WALK_TMAX_NOLOD" if lod_mode == 0 else "VRC_WALK_TMAX_LOD",
            "COUNTPART": "VRC_WALK_COUNT_LANE" if count_lane else "VRC_WALK_COUNT_WAVE",
            "BIASPART": "VRC_WALK_BIAS_ADD" if lod_mode == 2 else "VRC_WALK_BIAS_NONE"}
-    # the load form that is compiled by default (#else branch)
-    load_default = re.search(r"#else\s*\n#define VRC_WALK_LOAD_NODE (.*?)\n", src).group(1)
 
     def rec(text):
         res = []
@@ -115,8 +133,6 @@ def expand(src, lod_mode, count_lane):
                 name = sub.get(val, val)
                 if name in ("ROWSH", "ROWDOWN"):          # macro arguments that are string literals (the stack's row stride)
                     res.append("11" if name == "ROWSH" else "0xfffff800")
-                elif name == "VRC_WALK_LOAD_NODE":
-                    res.extend(rec(load_default))
                 else:
                     res.extend(rec(macro_body(src, name)))
         return res
@@ -124,7 +140,7 @@ def expand(src, lod_mode, count_lane):
 
 
 def block_counts(lod_mode=0, count_lane=False):
-    src = open(WALK).read()
+    src = preprocess(open(WALK).read())
     text = expand(src, lod_mode, count_lane)
     blocks = {"prologue": {}, "header": {}, "descend": {}, "advance": {}, "pop": {}, "start": {}, "epilogue": {}}
     in_start = False                  # the second half of the pop block is also the entry of rays that start below the root
@@ -184,7 +200,7 @@ def floor_cycles(valu, slow, p, scalar):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--freq", default=os.path.join(ROOT, "profiles", "r03", "walk_block_frequencies_c3.json"))
+    ap.add_argument("--freq", default=os.path.join(ROOT, "profiles", "r05", "walk_block_frequencies_c3_quad.json"))
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "issue_model.json"))
     a = ap.parse_args()
     sys.path.insert(0, ROOT)
