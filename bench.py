@@ -67,6 +67,7 @@ CONFIGS = {
                label="1024^3 LSVO terrain, 3840x2160, 16 spp GI"),
 }
 ROW_BLOCK = 8
+FORM_LABEL = {"root": "RCCL gather to rank 0", "all": "RCCL all-gather", "peer": "direct peer writes into rank 0's framebuffers (hipIpc), no collective"}
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -325,7 +326,13 @@ def free_port():
         return s.getsockname()[1]
 
 
-def launch_ranks(n, argv, popen=None, grace_s=20.0):
+def other_exchange_forms(headline, world, no_extras=False):
+    """the exchange forms a run measures after its timed region (extra.exchange_forms), in order: the two that are not the
+    headline form; none at N = 1 or with --no-extras"""
+    return [] if world <= 1 or no_extras else [f for f in ("root", "all", "peer") if f != headline]
+
+
+def launch_ranks(n, argv, popen=None, grace_s=20.0, plan_extra=None):
     """`python bench.py --gpus N` without a launcher: start N children (fresh processes -- never an exec of this one), one
     rank per GPU, and join them.  This process imports nothing that can initialise the GPU.  Rank 0 inherits stdout (its
     JSON line is the last line of ours); the other ranks' stdout goes to our stderr.  When a rank fails, the others get
@@ -342,7 +349,7 @@ def launch_ranks(n, argv, popen=None, grace_s=20.0):
     if os.environ.get("VRC_BENCH_LAUNCH_DRYRUN") == "1":         # tests/test_bench_launch.py: the plan, nothing started
         keys = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "HSA_ENABLE_IPC_MODE_LEGACY")
         print(json.dumps({"argv": [sys.executable, os.path.abspath(__file__)] + list(argv), "ranks": [{k: e.get(k) for k in keys} for e in envs],
-                          "torch_imported": "torch" in sys.modules, "modules_touching_gpu": sorted(m for m in sys.modules if m.split(".")[0] in ("torch", "cpuvoxelraycaster_amd", "ctypes"))}))
+                          "after_timed_region": plan_extra, "torch_imported": "torch" in sys.modules, "modules_touching_gpu": sorted(m for m in sys.modules if m.split(".")[0] in ("torch", "cpuvoxelraycaster_amd", "ctypes"))}))
         return 0
     procs = []
     for r, e in enumerate(envs):
@@ -438,8 +445,9 @@ def main():
                     help="N > 1: how the RGBA8 row-block shards meet: 'root' (default) = RCCL gather to rank 0, the presenting rank "
                          "(north_star / SURVEY 8e 'RCCL gather of the RGBA8 framebuffer': every other rank sends its shard over one "
                          "direct xGMI hop, 1/N of the all-gather's bytes on the wire), 'all' = RCCL all-gather (every rank ends up "
-                         "with the frame; measured right after the timed region as extra.other_exchange_form), 'peer' = no collective: every rank's frame kernel writes its rows straight into "
-                         "rank 0's framebuffer (hipIpc mapping over xGMI, interprocess events; SURVEY 8e 'direct peer writes')")
+                         "with the frame), 'peer' = no collective: every rank's frame kernel writes its rows straight into "
+                         "rank 0's framebuffer (hipIpc mapping over xGMI, frame flags in shared memory; SURVEY 8e 'direct peer writes').  The two forms not "
+                         "chosen are measured right after the timed region: extra.exchange_forms")
     ap.add_argument("--fused", default="auto", choices=["auto", "0", "1"],
                     help="resolve + pack + reset inside the frame kernel (vrc_render_frame_resolved) instead of a second kernel; "
                          "auto = whenever frames overlap (whole-spp work units: the fused path then resolves from registers, "
@@ -453,14 +461,19 @@ def main():
                          "4 = 4 x 4 pixels x 4 samples abreast, 0 = the library's choice")
     ap.add_argument("--no-quad", action="store_true",
                     help="A/B: vrc_renderer_set_quad_walks(0) -- the pinhole kernel's sample-invariant walks in the plain 8 x 8 x 1 layout")
-    ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra measurements (2-bounce extension)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra measurements (2-bounce extension; N > 1: the other exchange forms)")
+    ap.add_argument("--forms-deadline-s", type=float, default=240.0,
+                    help="N > 1: the untimed block that measures the other exchange forms (extra.exchange_forms) may take this long; after it "
+                         "rank 0 prints the headline line it already has and every rank leaves")
     ap.add_argument("--tuning", default="", help="blocks_per_cu: workgroups of the frame kernel per CU (= which waves-per-SIMD build), 0 = the library's choice")
     args = ap.parse_args()
 
     # the fork/join of main.cpp:139-154 across GPUs: plain `python bench.py --gpus N` starts its own ranks -- decided here,
     # before torch (or anything else that can touch the GPU) is imported
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:], plan_extra={
+            "headline_exchange": args.gather, "exchange_forms_measured_by_the_same_ranks": other_exchange_forms(args.gather, args.gpus, args.no_extras),
+            "forms_deadline_s": args.forms_deadline_s, "processes_started_for_them": 0}))
 
     import numpy as np
     import torch
@@ -565,7 +578,8 @@ def main():
     n_slots = 2 if F == 1 else F + 2
 
     ev_pairs = []
-    state = {"i": 0, "pending": [None] * n_slots, "last_slot": 0, "gather": args.gather}
+    # ("base": the frame the current PeerFrames segment counts from -- its flags start at zero, the frame counter does not)
+    state = {"i": 0, "pending": [None] * n_slots, "last_slot": 0, "gather": args.gather, "base": 0}
     peers = None
     if dist_on and args.gather == "peer":
         # rank 0's F renderers own the framebuffers; the other ranks' renderers write their rows into them
@@ -596,8 +610,9 @@ def main():
         slot = i % n_slots
         with torch.cuda.stream(ts):
             stream = ts.cuda_stream
+            pf = i - state["base"]                             # the frame's number in the peer-write flags (a multiple of F below i)
             if peers is not None:
-                peers.before_render(i, stream)                 # rank 0 has consumed the frame this framebuffer held
+                peers.before_render(pf, stream)                # rank 0 has consumed the frame this framebuffer held
             elif dist_on:
                 finish_gather(slot)                            # the frame that used this slot's buffers last
             # (frame_override: which frame's samples are rendered -- the slot / flag sequence still follows i; the N > 1 parity bit
@@ -623,8 +638,8 @@ def main():
             if peers is not None:
                 if not fused:
                     rc.resolveShard(ROW_BLOCK, rank, world, None, reset=True, stream=stream)
-                peers.after_render(i, stream)                  # rank 0: the frame is complete on this stream after the call
-                peers.consumed_on(i, stream)                   # (nothing reads it here: a presenter would, before this line)
+                peers.after_render(pf, stream)                 # rank 0: the frame is complete on this stream after the call
+                peers.consumed_on(pf, stream)                  # (nothing reads it here: a presenter would, before this line)
                 state["last_slot"] = i % F
             elif dist_on:
                 if not fused:                                      # (fused: resolved, packed and reset by the frame kernel)
@@ -746,8 +761,7 @@ def main():
     # the parity bit at N > 1 (round-4 verdict, Next 2a): frame 0 once more THROUGH THE EXCHANGE -- every rank renders its rows of
     # frame 0 with the timed renderers and settings, the shards meet the timed way -- and rank 0 compares the gathered frame and
     # the ranks' summed counters with the oracle's frame 0 (below, where the line is put together)
-    frame0 = None
-    if dist_on and world > 1 and not args.no_oracle_frame:
+    def frame0_through_exchange():
         for r in rcs:
             r.stats(reset=True, stream=tstreams[0].cuda_stream)
         dist.barrier()
@@ -756,44 +770,16 @@ def main():
         c0 = torch.tensor([sum(r.stats(stream=tstreams[0].cuda_stream).rays for r in rcs),
                            sum(r.stats(stream=tstreams[0].cuda_stream).sum_complexity for r in rcs)], dtype=torch.int64, device="cuda")
         dist.all_reduce(c0, op=dist.ReduceOp.SUM)
+        got = None
         if rank == 0:
             got0 = rcs[state["last_slot"]].readImage(stream) if peers is not None else full[state["last_slot"]].cpu().numpy().reshape(H, W, 4)
-            frame0 = (got0.copy(), int(c0[0].item()), int(c0[1].item()))
+            got = (got0.copy(), int(c0[0].item()), int(c0[1].item()))
         dist.barrier()                                         # (peer writes: nobody overwrites rank 0's framebuffer before it is read)
+        return got
 
-    # extra, N > 1 on RCCL: the same frames with the OTHER exchange form (all-gather <-> gather to rank 0), so that one
-    # driver run records both (not part of `value`)
-    other = None
-    if dist_on and backend == "nccl" and peers is None:
-        try:
-            state["gather"] = "root" if args.gather == "all" else "all"
-            n_o = max(5, min(args.steps, 30))
-            for _ in range(3):
-                step(False)
-            drain()
-            dist.barrier()
-            torch.cuda.synchronize()
-            t_o = time.perf_counter()
-            for _ in range(n_o):
-                step(False)
-            drain()
-            dist.barrier()
-            torch.cuda.synchronize()
-            dt_o = torch.tensor([time.perf_counter() - t_o], dtype=torch.float64, device="cuda")
-            dist.all_reduce(dt_o, op=dist.ReduceOp.MAX)
-            ok_o = None
-            if rank == 0:
-                ref = make_renderer()
-                ref.frame_index = (state["i"] - 1) * spp
-                ref.renderFrame(cam, spp=spp, stream=stream)
-                ref.samples_to_image(stream)
-                torch.cuda.synchronize()
-                ok_o = bool(np.array_equal(full[state["last_slot"]].cpu().numpy().reshape(H, W, 4), ref.readImage(stream)))
-            other = {"exchange": "gather to rank 0" if state["gather"] == "root" else "all-gather", "steps": n_o,
-                     "ms_per_step": round(float(dt_o.item()) / n_o * 1e3, 4), "gathered_frame_equals_unsharded": ok_o}
-        except Exception as e:                                 # noqa: BLE001  (never lose the main result to the extra)
-            other = {"exchange": state["gather"], "error": repr(e)[:300]}
-        state["gather"] = args.gather
+    frame0 = None
+    if dist_on and world > 1 and not args.no_oracle_frame:
+        frame0 = frame0_through_exchange()
 
     # N > 1: the chip time per launch above spans this rank's exchange / unpack kernels and waits as well: time the
     # frame kernel of this rank's shard on its own, untimed extra, same renderers / streams / unit policy, no exchange
@@ -1018,6 +1004,7 @@ def main():
                     "pixel and frame instead of once per sample; same image bit for bit; same frames in flight and unit policy as the "
                     "timed region (whole-spp units make the reuse span the frame's samples), measured right after it"}
 
+    out = oracle0 = None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         # roofline of the dominant kernel (k_render_sync*), this rank's launches:
@@ -1131,6 +1118,15 @@ def main():
                             "the kernel's own streams issue at about that rate, i.e. only fewer instructions (or fuller lanes, see lane_utilisation) make the frame faster"})
             if walks_model:
                 issue.update({"valu_wave_instr_walks_model": int(walk_valu), "slow_class_wave_instr_walks_model": int(slow)})
+                if model.get("lane_utilisation_by_stage"):
+                    issue["lane_utilisation_by_stage"] = dict(model["lane_utilisation_by_stage"])
+                    issue["lane_utilisation_by_stage_note"] = (
+                        "live lanes per issued walk-loop header, stage by stage, from the oracle's per-iteration traces of this workload "
+                        "(profiles/issue_model.json <- " + model["frequencies"] + "); lane_utilisation above is the PMC average over the whole "
+                        "launch.  With the pinhole camera the reference casts a pixel's primary ray and the shadow ray of its hit once per "
+                        "sample (raycaster.hpp:131,147-158; the jitter is commented out at :151): in the quadrant layout those identical walks sit "
+                        f"side by side, so (spp - 1) / spp = {spp - 1}/{spp} of the primary / shadow stages' live lanes are lockstep copies -- see "
+                        "config.rays_distinct_per_frame.  The GI stages' rays are all distinct")
             roof["bound"] = "valu_issue"
             roof["bound_note"] = ("instruction issue (roofline.issue) is what binds; achieved / peak / frac keep the nominal HBM form SURVEY 8d "
                                   "asks for (algorithmic bytes / kernel time), traffic is the measured HBM traffic")
@@ -1169,14 +1165,22 @@ def main():
                        "frame_equals_oracle": None},
             "roofline": roof,
         }
-        if other is not None:
-            if "ms_per_step" in other:
-                other["value"] = round(rays / args.steps / (other["ms_per_step"] * 1e-3) / 1e6, 2)
-            extras["other_exchange_form"] = other
         extras["ms_per_step_blocks"] = {"min_median_max": [round(min(block_ms), 4), round(sorted(block_ms)[len(block_ms) // 2], 4), round(max(block_ms), 4)],
                                         "blocks": len(block_ms), "steps_per_block": args.steps,
                                         "note": "every block is `steps` frames between barrier + synchronize on both sides; ms_per_step, value and the "
                                                 "roofline are those of the median block"}
+        if "invariant_rays_walked_once" in extras:
+            # which of the work is distinct (round-5 verdict, Next 3): `value` counts every ray the reference casts; a pinhole
+            # camera's primary and shadow ray are the same for every sample of a pixel, so part of them are identical walks
+            inv = extras["invariant_rays_walked_once"]
+            out["config"]["rays_distinct_per_frame"] = inv["rays_per_frame_executed"]
+            out["config"]["ms_per_identical_image"] = inv["ms_per_step"]
+            out["config"]["rays_distinct_note"] = (
+                f"of the {rays // args.steps} rays per frame the reference casts (and `value` counts, each walked by a lane of its own), "
+                f"{rays // args.steps - inv['rays_per_frame_executed']} are repeats of a pixel's sample-invariant primary / shadow walk "
+                "(raycaster.hpp:131,147-158); rays_distinct_per_frame = the walks left when each is done once per pixel and frame, "
+                "ms_per_identical_image = the frame period of that mode (vrc_renderer_set_invariant_ray_reuse, off by default, bit-identical "
+                "image; measured right after the timed region: extra.invariant_rays_walked_once)")
         if extras:
             out["extra"] = extras
         if frame0 is not None:
@@ -1189,6 +1193,7 @@ def main():
             ref_img, ref_rays, ref_sumc = oracle_frame(cfg, svo.downloadNodes(), textures, cam, light, min(64, usable_cores))
             got0, rays0, sumc0 = frame0
             frame_ok = bool(np.array_equal(got0, ref_img)) and (rays0, sumc0) == (ref_rays, ref_sumc)
+            oracle0 = (ref_img, ref_rays, ref_sumc)                # (the other exchange forms' gathered frames meet the same one)
             out["config"]["frame_equals_oracle"] = frame_ok
             out["config"]["frame_equals_oracle_is"] = (
                 f"frame 0 ({spp} samples of all {W * H} pixels) rendered once more after the timed region by the {world} ranks' timed renderers "
@@ -1222,6 +1227,111 @@ def main():
                 f"{ref_sumc}; oracle time {time.perf_counter() - t_or:.1f} s")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, svo.downloadNodes(), textures, cam, light)
+    # N > 1, untimed extra (round-5 verdict, Next 2): ONE invocation reports all three exchange forms.  After the timed region
+    # (the headline form, --gather) the SAME ranks, renderers, streams and buffers run a short block of frames (3 blocks of
+    # `steps`, median) for each of the other forms -- RCCL gather to rank 0, RCCL all-gather, direct peer writes -- each with its
+    # own gathered-frame-0-equals-the-oracle bit and every rank's host wait for its exchange to empty.  A form that cannot be
+    # set up (hipIpc refused ...) records its error and the run goes on; nothing here can change `value`, and a deadline guards
+    # the headline: if the extras have not finished after --forms-deadline-s seconds, rank 0 prints the line it already has
+    # (with the reason in extra.exchange_forms) and every rank leaves by itself.  No process is started or replaced.
+    if dist_on and world > 1 and not args.no_extras:
+        forms = {}
+        if rank == 0:
+            forms[args.gather] = {
+                "exchange": FORM_LABEL[args.gather], "headline": True, "ms_per_step": out["ms_per_step"], "value": out["value"],
+                "steps": args.steps, "blocks": len(block_ms), "frame_equals_oracle": out["config"].get("frame_equals_oracle"),
+                "gathered_frame_equals_unsharded": verified,
+                "per_rank_exchange_wait_ms": [p_["drain_wait_ms_per_block"] for p_ in per_rank],
+                "per_rank_exchange_ms_per_step": [p_["exchange_ms_per_step"] for p_ in per_rank]}
+            out.setdefault("extra", {})["exchange_forms"] = forms
+        dist.barrier()                                         # rank 0 has put the headline line together (oracle frame): the clock starts for everyone
+
+        def give_up():
+            why = f"the other exchange forms did not finish within {args.forms_deadline_s:.0f} s; the headline measurement above is complete"
+            try:
+                if rank == 0:
+                    forms["deadline"] = why
+                    sys.stdout.flush()
+                    print(json.dumps(out), flush=True)
+                print(f"bench.py: rank {rank}: {why}", file=sys.stderr, flush=True)
+                if _PEER_EXCHANGE:
+                    _PEER_EXCHANGE[0].wait(_PEER_EXCHANGE[1], timeout_s=5.0)      # no stream-ordered flag wait stays behind on the device
+            except BaseException:                                 # noqa: BLE001
+                pass
+            os._exit(0 if out is None or out["config"].get("frame_equals_oracle") is not False else 1)
+        import threading
+        guard = threading.Timer(args.forms_deadline_s, give_up)
+        guard.daemon = True
+        guard.start()
+
+        def close_peers():
+            nonlocal peers
+            if peers is not None:
+                dist.barrier()
+                peers.close()
+                peers = None
+                del _PEER_EXCHANGE[:]
+                dist.barrier()
+
+        n_f = max(3, min(args.steps, 100))
+        for form in other_exchange_forms(args.gather, world):
+            rec = {"exchange": FORM_LABEL[form], "headline": False, "steps": n_f}
+            try:
+                close_peers()
+                state["gather"] = form
+                if form == "peer":
+                    state["i"] += (-state["i"]) % F                 # renderer / framebuffer i % F == flag slot (i - base) % F
+                    state["base"] = state["i"]
+                    peers = vdist.PeerFrames(rcs, local_rank, rank, world, dist.group.WORLD,
+                                             "/vrc_bench_peer_%s_x" % os.environ.get("MASTER_PORT", "0"))
+                    _PEER_EXCHANGE[:] = [peers, [ts.cuda_stream for ts in tstreams]]
+                for _ in range(max(F, 3)):
+                    step(False)
+                drain()
+                runs = []
+                for _blk in range(3):
+                    dist.barrier()
+                    torch.cuda.synchronize()
+                    t_f = time.perf_counter()
+                    for _ in range(n_f):
+                        step(False)
+                    t_d = time.perf_counter()
+                    drain()
+                    wait_ms = (time.perf_counter() - t_d) * 1e3
+                    dist.barrier()
+                    torch.cuda.synchronize()
+                    dt_f = torch.tensor([time.perf_counter() - t_f], dtype=torch.float64, device="cuda")
+                    dist.all_reduce(dt_f, op=dist.ReduceOp.MAX)
+                    runs.append((float(dt_f.item()) / n_f * 1e3, wait_ms))
+                med_f = sorted(runs)[len(runs) // 2]
+                waits = [None] * world
+                dist.all_gather_object(waits, round(med_f[1], 3))
+                rec.update({"ms_per_step": round(med_f[0], 4), "ms_per_step_blocks": [round(r_[0], 4) for r_ in sorted(runs)], "blocks": len(runs),
+                            "per_rank_exchange_wait_ms": waits})
+                if not args.no_oracle_frame:
+                    got_f = frame0_through_exchange()
+                    if rank == 0 and oracle0 is not None:
+                        rec["frame_equals_oracle"] = bool(np.array_equal(got_f[0], oracle0[0])) and (got_f[1], got_f[2]) == (oracle0[1], oracle0[2])
+                if rank == 0:
+                    rec["value"] = round(out["config"]["rays_per_frame"] / (rec["ms_per_step"] * 1e-3) / 1e6, 2)
+            except Exception as e:                                 # noqa: BLE001  (never lose the main result to an extra)
+                rec["error"] = repr(e)[:400]
+            if rank == 0:
+                forms[form] = rec
+        try:
+            close_peers()
+        except Exception as e:                                     # noqa: BLE001
+            if rank == 0:
+                forms["close_error"] = repr(e)[:300]
+        state["gather"] = args.gather
+        guard.cancel()
+        if rank == 0:
+            forms["note"] = ("the headline form is the timed region (`value`); the others ran right after it on the same ranks, renderers and "
+                             f"buffers: median of 3 blocks of {n_f} frames between barrier + synchronize, untimed extras.  per_rank_exchange_wait_ms = "
+                             "each rank's host wait, after issuing a block, for its own streams and exchanges to empty; frame_equals_oracle = frame 0 "
+                             "rendered once more through THAT exchange, gathered image and summed counters vs the oracle's"
+                             + ("" if backend == "nccl" else f".  REHEARSAL on {backend}: 'root' and 'all' are the same host-staged all_gather here; "
+                                                             "only the control flow and the parity bits mean anything"))
     if dist_on:
         dist.barrier()
     if peers is not None:

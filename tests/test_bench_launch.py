@@ -27,6 +27,20 @@ def test_parent_plans_n_ranks_and_never_imports_torch():
     assert {r["WORLD_SIZE"] for r in ranks} == {"8"} and {r["MASTER_ADDR"] for r in ranks} == {"127.0.0.1"}
     assert len({r["MASTER_PORT"] for r in ranks}) == 1 and int(ranks[0]["MASTER_PORT"]) > 0
     assert {r["HSA_ENABLE_IPC_MODE_LEGACY"] for r in ranks} == {"0"}
+    # round-5 verdict, Next 2: the one invocation measures all three exchange forms -- the headline in the timed region, the
+    # other two right after it by the same ranks (no process is started for them), behind a deadline
+    after = plan["after_timed_region"]
+    assert after["headline_exchange"] == "root" and after["exchange_forms_measured_by_the_same_ranks"] == ["all", "peer"]
+    assert after["processes_started_for_them"] == 0 and after["forms_deadline_s"] > 0
+
+
+def test_the_other_exchange_forms_follow_the_headline_form():
+    import bench
+    assert bench.other_exchange_forms("root", 8) == ["all", "peer"]
+    assert bench.other_exchange_forms("all", 2) == ["root", "peer"]
+    assert bench.other_exchange_forms("peer", 4) == ["root", "all"]
+    assert bench.other_exchange_forms("root", 1) == [] and bench.other_exchange_forms("root", 8, no_extras=True) == []
+    assert set(bench.FORM_LABEL) == {"root", "all", "peer"}
 
 
 def test_ipc_mode_of_the_ranks_is_inherited_and_only_defaulted_when_unset():

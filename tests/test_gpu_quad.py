@@ -73,15 +73,36 @@ def test_quadrant_walks_equal_the_plain_kernel(scene, size, spp, chunk, shadows)
                    (sb.rays, sb.sum_complexity, sb.pixels, sb.primary_hits, sb.iterations_not_executed), what
 
 
-def test_quadrant_walks_equal_oracle(scene, textures):
+_SCENES = {}
+
+
+def scene_at(vrc, heights, textures, depth):
+    if depth not in _SCENES:
+        nodes = vrc.build_terrain_lsvo(heights, depth)
+        _SCENES[depth] = (nodes, vrc.LSVO(nodes, depth, textures=textures))
+    return _SCENES[depth]
+
+
+# (spp, chunk, shadow_samples, gi_bounces, depth): 4 / 8 / 16 lanes per pixel (quad_lanes_lg), the 16-lane shadow walks of two
+# shadow samples, no shadow ray at all, and the 2-bounce _q kernels -- each DIRECTLY against orc_render_frame (round-5 verdict,
+# Next 1b; before, only (4, 4, 1, 1, 8) met the oracle and the others met the plain kernel)
+@pytest.mark.parametrize("spp,chunk,shadows,bounces,depth", [(4, 4, 1, 1, 8), (8, 8, 1, 1, 8), (16, 16, 1, 1, 9), (4, 4, 0, 1, 8),
+                                                              (8, 8, 2, 1, 9), (4, 4, 1, 2, 8), (16, 8, 4, 1, 8)])
+def test_quadrant_walks_equal_oracle(built, heights, textures, spp, chunk, shadows, bounces, depth):
+    """raycaster.hpp:131,147-158: one primary cast and `shadow_sample` shadow casts per sample, every one of them walked by a
+    lane of its own in the quadrant layout: image, rays and loop iterations of three consecutive frames vs the oracle"""
     import torch
     import cpuvoxelraycaster_amd as vrc
-    nodes, svo = scene
+    nodes, svo = scene_at(vrc, heights, textures, depth)
     top, side = textures
-    W, H, spp = 161, 91, 4
-    cam = vrc.reference_camera(D, pitch=-0.5)
-    rc = make(vrc, svo, W, H, spp)
-    light = vrc.reference_light(D)
+    W, H = (161, 91) if spp <= 8 else (97, 61)
+    cam = vrc.reference_camera(depth, pitch=-0.5)
+    rc = vrc.RayCaster(svo, (W, H))
+    light = vrc.reference_light(depth)
+    rc.setLightPosition(light)
+    rc.use_gi, rc.use_samples, rc.shadow_samples, rc.gi_bounces = True, True, shadows, bounces
+    rc.setSampleChunk(chunk)
+    rc.setLaneSamples(1)
     ocam = O.make_camera(tuple(cam.position), tuple(cam.rot), cam.fov, cam.aperture, cam.focal_length)
     rays = steps = 0
     for frame in range(3):
@@ -90,14 +111,14 @@ def test_quadrant_walks_equal_oracle(scene, textures):
         torch.cuda.synchronize()
         acc = None
         for s in range(spp):
-            p = O.make_params(W, H, light, use_gi=1, use_samples=1, shadow_samples=1, frame_index=frame * spp + s)
-            _, acc, _, st = O.render_frame(nodes, D, top, side, ocam, p, accum=acc, threads=8)
+            p = O.make_params(W, H, light, use_gi=1, use_samples=1, shadow_samples=shadows, frame_index=frame * spp + s, gi_bounces=bounces)
+            _, acc, _, st = O.render_frame(nodes, depth, top, side, ocam, p, accum=acc, threads=8)
             rays += st.rays
             steps += st.sum_complexity
         assert np.array_equal(rc.readImage(), O.samples_to_image(acc)), frame
     st = rc.stats()
     assert (st.rays, st.sum_complexity) == (rays, steps)
-    assert rc.lastKernel().endswith("_q")
+    assert rc.lastKernel() == ("k_render_sync_pinhole_resolved_q" if bounces == 1 else "k_render_sync_pinhole2_resolved_q")
 
 
 def test_two_bounce_extension_and_fallbacks(scene):

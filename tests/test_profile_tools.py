@@ -141,3 +141,41 @@ def test_path_schedule_policies_on_a_synthetic_walk():
         assert lanes[blocks == 0].sum() == int(length.sum())          # every lane-iteration went through one header
     finally:
         ps.MASKS = None
+
+
+def test_scale_report_attributes_a_curve_to_balance_and_exchange(tmp_path):
+    """tools/scale_report.py (round-5 verdict, Next 2): four bench lines in, one table out -- efficiency against N = 1 and
+    against the compute-only ceiling of one rank's shard (profiles/r05/shard_inflight_final.txt), and the exchange forms a
+    line carries.  Synthetic lines: N = 2 exactly at its ceiling (all of its loss is balance), N = 8 at twice its ceiling
+    (half of its time is exchange)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import scale_report as sr
+    wl = "512^3 LSVO terrain (FastNoise seed 1337, generated and built on the GPU), 1920x1080, 4 spp GI (1 indirect bounce), shadow_samples=1"
+    rays = 32222738
+
+    def line(n, ms, forms=None):
+        d = {"metric": "m", "n_gpus": n, "ms_per_step": ms, "value": rays / (ms * 1e-3) / 1e6,
+             "config": {"workload": wl, "frame_equals_oracle": True, "sharding": f"8-row blocks round-robin over {n} GPU(s), RCCL gather to rank 0 of RGBA8 shards"}}
+        if forms:
+            d["extra"] = {"exchange_forms": forms}
+        return d
+    forms8 = {"root": {"headline": True, "ms_per_step": 0.2568, "value": 1.0e5, "frame_equals_oracle": True, "per_rank_exchange_wait_ms": [0.1] * 8},
+              "all": {"headline": False, "ms_per_step": 0.30, "value": 9.0e4, "frame_equals_oracle": True, "per_rank_exchange_wait_ms": [0.2] * 8},
+              "peer": {"headline": False, "error": "VrcError('hipIpcOpenMemHandle refused')"}}
+    lines = [line(1, 0.9066), line(2, 0.4724), line(4, 0.2491 * 1.25), line(8, 0.2568, forms8)]
+    paths = []
+    for d in lines:
+        p = tmp_path / f"n{d['n_gpus']}.json"
+        p.write_text("RCCL banner line\n" + json.dumps(d) + "\n")            # the JSON line is the LAST line of a log
+        paths.append(str(p))
+    (tmp_path / "rec.json").write_text(json.dumps({"rc": 0, "parsed": lines[0]}))    # a driver record holds it under "parsed"
+    assert sr.load_line(str(tmp_path / "rec.json"))["n_gpus"] == 1
+    text, rows = sr.report([sr.load_line(p) for p in reversed(paths)])
+    by_n = {r["n"]: r for r in rows}
+    assert abs(by_n[2]["eff_ceiling"] - 1.0) < 1e-6 and abs(by_n[2]["eff"] - 906.6 / 472.4 / 2) < 1e-3
+    assert abs(by_n[4]["eff_ceiling"] - 0.8) < 1e-6
+    assert abs(by_n[8]["eff_ceiling"] - 0.5) < 1e-3 and abs(by_n[8]["speedup"] - 0.9066 / 0.2568) < 1e-6
+    assert "balance 11.7% exch  50.0%" in text
+    assert "peer  FAILED: VrcError" in text and "<- headline" in text and "all      0.3000 ms/frame" in text
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "scale_report.py")] + paths, text=True)
+    assert out == text

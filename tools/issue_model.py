@@ -213,6 +213,12 @@ def main():
            "source_hash": bench.kernel_source_hash(), "frequencies": os.path.relpath(a.freq, ROOT), "workload": freq["workload"],
            "blocks_no_lod": nolod, "blocks_lod": lod,
            "walks_per_tile_sample": {k: round(v, 2) for k, v in pts.items()},
+           # live lanes per issued loop header, stage by stage (a header is issued when any of the wave's 64 lanes iterates): what
+           # roofline.issue.lane_utilisation averages over.  In the quadrant layout the primary and shadow stages' lanes are one
+           # pixel's `spp` identical walks side by side (raycaster.hpp:131,153 cast them once per sample), so their high figures
+           # are three-quarters copies at 4 spp; the GI stages' rays are all distinct
+           "lane_utilisation_by_stage": {{"primary": "primary", "shadow": "shadow", "GI": "gi", "GI shadow": "gi_shadow"}[k]:
+                                         round(v["lane_iterations"] / (64.0 * v["header"]), 4) for k, v in freq["stages"].items()},
            "cycles": {"valu_arch": CYC_VALU_ARCH, "valu_measured_ceiling": CYC_VALU_MEASURED, "slow": CYC_SLOW, "p": CYC_P,
                       "salu_per_cu": CYC_SALU_PER_CU}}
     json.dump(doc, open(a.out, "w"), indent=1)
