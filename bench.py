@@ -1246,20 +1246,28 @@ def main():
             out.setdefault("extra", {})["exchange_forms"] = forms
         dist.barrier()                                         # rank 0 has put the headline line together (oracle frame): the clock starts for everyone
 
+        why = f"the other exchange forms did not finish within {args.forms_deadline_s:.0f} s; the headline measurement above is complete"
+        fallback_line = None
+        if rank == 0:                                              # the line as it stands, serialised NOW: the timer thread touches nothing the main thread writes
+            fb = dict(out)
+            fb["extra"] = dict(out["extra"], exchange_forms={args.gather: forms[args.gather], "deadline": why})
+            fallback_line = json.dumps(fb)
+        import threading
+        finishing = threading.Lock()                               # whoever holds it prints the line: the timer thread or the main thread, never both
+
         def give_up():
-            why = f"the other exchange forms did not finish within {args.forms_deadline_s:.0f} s; the headline measurement above is complete"
+            if not finishing.acquire(blocking=False):
+                return                                             # the forms are done and the main thread is on its way out
             try:
                 if rank == 0:
-                    forms["deadline"] = why
                     sys.stdout.flush()
-                    print(json.dumps(out), flush=True)
+                    print(fallback_line, flush=True)
                 print(f"bench.py: rank {rank}: {why}", file=sys.stderr, flush=True)
                 if _PEER_EXCHANGE:
                     _PEER_EXCHANGE[0].wait(_PEER_EXCHANGE[1], timeout_s=5.0)      # no stream-ordered flag wait stays behind on the device
             except BaseException:                                 # noqa: BLE001
                 pass
             os._exit(0 if out is None or out["config"].get("frame_equals_oracle") is not False else 1)
-        import threading
         guard = threading.Timer(args.forms_deadline_s, give_up)
         guard.daemon = True
         guard.start()
@@ -1325,6 +1333,9 @@ def main():
                 forms["close_error"] = repr(e)[:300]
         state["gather"] = args.gather
         guard.cancel()
+        if not finishing.acquire(blocking=False):                  # the deadline fired a moment ago: that thread prints and leaves
+            time.sleep(60.0)
+            os._exit(0)
         if rank == 0:
             forms["note"] = ("the headline form is the timed region (`value`); the others ran right after it on the same ranks, renderers and "
                              f"buffers: median of 3 blocks of {n_f} frames between barrier + synchronize, untimed extras.  per_rank_exchange_wait_ms = "

@@ -49,6 +49,22 @@ def test_plain_bench_line_launches_its_ranks(built, world, gather):
         f.write(json.dumps(d) + "\n")
 
 
+def test_the_extras_deadline_keeps_the_headline_line(built):
+    """round 6: the block that measures the other exchange forms is untimed and must never cost the run its result.  With a
+    deadline of 50 ms it cannot finish: rank 0 prints the headline line it already has -- parity bit and all, the reason under
+    extra.exchange_forms.deadline -- as the LAST line of stdout, and every rank leaves by itself with exit code 0."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["VRC_DIST_BACKEND"] = "gloo"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--blocks", "1",
+                          "--blocks-min-seconds", "0", "--config", "c4", "--forms-deadline-s", "0.05"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 2 and d["config"]["frame_equals_oracle"] is True and d["value"] > 0
+    forms = d["extra"]["exchange_forms"]
+    assert "did not finish within" in forms["deadline"] and forms["root"]["headline"] is True and set(forms) == {"root", "deadline"}
+    assert "did not finish within" in out.stderr
+
+
 def test_nccl_on_too_few_gpus_fails_loudly(built):
     """RCCL needs one GPU per rank: on this one-GPU box the plain line must leave non-zero with the reason, not hang"""
     import torch
