@@ -266,9 +266,8 @@ def test_round5_headline_quotes_a_clean_rocprof_record_of_the_timed_symbol():
     alone = load5("final_bench_timed_symbol_alone.json.log")
     assert alone["config"]["frames_in_flight"] == 1 and alone["config"]["whole_spp_work_units"] is True
     assert alone["roofline"]["kernel"] == r["kernel"] and abs(alone["roofline"]["kernel_ms"] / r["kernel_ms_alone"] - 1.0) < 0.03
-    # the record is the one profiles/traffic.json holds for these kernel sources
-    rec = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["entries"]["c3_n1_inflight1_wholespp"]
-    assert abs(rec["profiled_kernel_ms"] - avg_ms) < 1e-3 and rec["kernel"] == r["kernel"] and rec["settings"]["frames_in_flight"] == 1
+    # (round 6 took the records again for its kernel-source hash: profiles/traffic.json now points at profiles/r06/, and
+    # test_round6_headline_... holds the same relations on that round's line)
 
 
 def test_round5_self_launched_lines_validate_themselves():
@@ -290,3 +289,79 @@ def test_round5_self_launched_lines_validate_themselves():
             assert "gloo" in c["sharding"] and "REHEARSAL" in c["sharding"] and "RCCL gather" not in c["sharding"]
         else:
             assert "direct peer writes" in c["sharding"]
+
+
+R6 = os.path.join(ROOT, "profiles", "r06")
+
+
+def load6(name):
+    with open(os.path.join(R6, name)) as f:
+        return json.loads(f.read().strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize("name", ["final_bench.json.log", "final_bench_steps20.json.log", "final_bench_c2.json.log", "final_bench_c4.json.log",
+                                  "final_bench_c5.json.log"])
+def test_round6_bench_line_contract(name):
+    d = load6(name)
+    for k, t in DRIVER_KEYS.items():
+        assert isinstance(d[k], t), k
+    assert d["vs_baseline"] is None and d["higher_is_better"] is True and d["unit"] == "Mrays/s" and d["n_gpus"] == 1
+    assert d["config"]["frame_equals_oracle"] is True
+    r = d["roofline"]
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and r["kernel_ms"] <= d["ms_per_step"] * 1.001
+    assert r["kernel_ms_alone"] > r["kernel_ms"] and d["extra"]["timed_symbol_alone"]["kernel"] == r["kernel"]
+    # the PMC record is this round's (taken again on this tree's kernel sources), and the --stats file it names exists
+    assert r["traffic"] is not None and r["traffic"] < 0.2 * r["algorithmic_bytes_per_launch"]        # (C2, a 0.07 ms frame: 6 MB of 0.3 GB; C3: 0.4 %)
+    assert r["traffic_detail"]["profile"].startswith("profiles/r06/") and os.path.exists(os.path.join(ROOT, r["traffic_detail"]["profile"]))
+    rp = r["kernel_ms_alone_rocprof"]
+    assert rp["profile"].startswith("profiles/r06/") and os.path.exists(os.path.join(ROOT, rp["profile"])) and rp["agrees_with_kernel_ms_alone_within_3pct"] is True
+    assert r["bound"] == "valu_issue" and 0.4 < r["issue"]["issue_frac"] <= 1.0             # (C2, a 0.07 ms launch that is mostly tail: 0.48; C3 0.78)
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+
+
+def test_round6_headline_says_which_work_is_distinct():
+    """round-5 verdict, Next 3: a reader of `value` and `lane_utilisation` must be able to tell that part of the rays are
+    lockstep copies of a pixel's sample-invariant walks (raycaster.hpp:131,147-158)"""
+    import csv
+    d = load6("final_bench.json.log")
+    c, r = d["config"], d["roofline"]
+    # (means over a block's frames, whose GI rays differ frame by frame: frame 0 alone has 32 222 738 rays, 12.4 M of them repeats)
+    assert abs(c["rays_per_frame"] - 32222738) < 5000 and abs(c["rays_distinct_per_frame"] - 19829529) < 5000
+    assert c["rays_distinct_per_frame"] == d["extra"]["invariant_rays_walked_once"]["rays_per_frame_executed"]
+    assert c["ms_per_identical_image"] == d["extra"]["invariant_rays_walked_once"]["ms_per_step"] < d["ms_per_step"]
+    assert "raycaster.hpp:131,147-158" in c["rays_distinct_note"]
+    by_stage = r["issue"]["lane_utilisation_by_stage"]
+    assert set(by_stage) == {"primary", "shadow", "gi", "gi_shadow"}
+    assert by_stage["primary"] > 0.9 and by_stage["shadow"] > 0.85 and by_stage["gi"] < 0.5 and by_stage["gi_shadow"] < 0.55
+    assert by_stage == json.load(open(os.path.join(ROOT, "profiles", "issue_model.json")))["lane_utilisation_by_stage"]
+    assert "lockstep copies" in r["issue"]["lane_utilisation_by_stage_note"]
+    assert min(by_stage.values()) < r["issue"]["lane_utilisation"] < max(by_stage.values())     # the PMC average lies between
+    # the headline's roofline figures, recomputed from the files it names
+    rp = r["kernel_ms_alone_rocprof"]
+    with open(os.path.join(ROOT, rp["profile"])) as f:
+        row = [x for x in csv.DictReader(f) if x["Name"].startswith("k_render")][0]
+    assert row["Name"] == r["kernel"] == "k_render_sync_pinhole_resolved_q" and int(row["Calls"]) >= 100
+    avg_ms = float(row["AverageNs"]) / 1e6
+    assert abs(r["algorithmic_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9 / 8000.0 / r["frac_alone"] - 1.0) < 0.03
+    rec = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["entries"]["c3_n1_inflight1_wholespp"]
+    assert abs(rec["profiled_kernel_ms"] - avg_ms) < 1e-3 and rec["kernel"] == r["kernel"] and rec["settings"]["frames_in_flight"] == 1
+
+
+@pytest.mark.parametrize("n", [2, 4, 8])
+def test_round6_one_invocation_reports_the_three_exchange_forms(n):
+    """round-5 verdict, Next 2 (done criterion): `VRC_DIST_BACKEND=gloo python3 bench.py --gpus N --steps 5` on the box -- rc 0,
+    three forms in extra.exchange_forms, every parity bit true.  (A rehearsal: the ranks share the box's one GPU and the
+    collectives are host-staged gloo; the peer writes are real hipIpc mappings.)"""
+    d = load6(f"exchange_forms_gloo{n}.json.log")
+    c = d["config"]
+    assert d["n_gpus"] == n and c["ranks_in_process_group"] == n and c["frame_equals_oracle"] is True and c["gathered_frame_equals_unsharded"] is True
+    forms = d["extra"]["exchange_forms"]
+    assert "deadline" not in forms and "close_error" not in forms
+    assert forms["root"]["headline"] is True and forms["root"]["ms_per_step"] == d["ms_per_step"] and forms["root"]["value"] == d["value"]
+    for name in ("root", "all", "peer"):
+        f = forms[name]
+        assert "error" not in f and f["frame_equals_oracle"] is True and f["ms_per_step"] > 0 and f["value"] > 0, (name, f)
+        assert len(f["per_rank_exchange_wait_ms"]) == n
+    assert "REHEARSAL" in forms["note"] and "rehearsal" in c["sharding"].lower()
+    assert c["exchange"]["backend"] == "gloo" and c["exchange"]["device_can_access_peer"] == [[1]]
