@@ -496,6 +496,9 @@ def main():
     # VRC_FORCE_DIST=1 takes the N > 1 code path (process group, shard buffers, all-gather, unpack) with a world of one
     # rank: the only way to run the RCCL calls of this file on a single-GPU box
     dist_on = world > 1 or os.environ.get("VRC_FORCE_DIST") == "1"
+    # ... and VRC_FORCE_FORMS=1 with it runs the N > 1 extras too (frame 0 through the exchange, extra.exchange_forms) with that
+    # world of one: RCCL's gather <-> all-gather switch and the peer-write set-up on the one GPU a box has
+    many = world > 1 or (dist_on and os.environ.get("VRC_FORCE_FORMS") == "1")
     if dist_on and world == 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -778,7 +781,7 @@ def main():
         return got
 
     frame0 = None
-    if dist_on and world > 1 and not args.no_oracle_frame:
+    if dist_on and many and not args.no_oracle_frame:
         frame0 = frame0_through_exchange()
 
     # N > 1: the chip time per launch above spans this rank's exchange / unpack kernels and waits as well: time the
@@ -1234,7 +1237,7 @@ def main():
     # set up (hipIpc refused ...) records its error and the run goes on; nothing here can change `value`, and a deadline guards
     # the headline: if the extras have not finished after --forms-deadline-s seconds, rank 0 prints the line it already has
     # (with the reason in extra.exchange_forms) and every rank leaves by itself.  No process is started or replaced.
-    if dist_on and world > 1 and not args.no_extras:
+    if dist_on and many and not args.no_extras:
         forms = {}
         if rank == 0:
             forms[args.gather] = {
@@ -1282,7 +1285,7 @@ def main():
                 dist.barrier()
 
         n_f = max(3, min(args.steps, 100))
-        for form in other_exchange_forms(args.gather, world):
+        for form in other_exchange_forms(args.gather, max(world, 2)):
             rec = {"exchange": FORM_LABEL[form], "headline": False, "steps": n_f}
             try:
                 close_peers()

@@ -365,3 +365,18 @@ def test_round6_one_invocation_reports_the_three_exchange_forms(n):
         assert len(f["per_rank_exchange_wait_ms"]) == n
     assert "REHEARSAL" in forms["note"] and "rehearsal" in c["sharding"].lower()
     assert c["exchange"]["backend"] == "gloo" and c["exchange"]["device_can_access_peer"] == [[1]]
+
+
+def test_round6_rccl_runs_the_three_forms_with_a_world_of_one():
+    """the only RCCL this project can run on a one-GPU box: VRC_FORCE_DIST=1 VRC_FORCE_FORMS=1 takes the N > 1 code path -- process
+    group on the nccl backend, shard buffers, the async gather / all-gather handles, the switch between the forms, PeerFrames'
+    set-up and flags -- with one rank.  Every form renders the oracle's frame 0; their periods are the N = 1 frame's."""
+    d = load6("force_forms_rccl_world1.json.log")
+    c = d["config"]
+    assert d["n_gpus"] == 1 and c["exchange"]["backend"] == "nccl" and c["exchange"]["rccl_version"][0].isdigit()
+    assert "RCCL gather to rank 0" in c["sharding"] and c["frame_equals_oracle"] is True
+    forms = d["extra"]["exchange_forms"]
+    for name in ("root", "all", "peer"):
+        assert "error" not in forms[name] and forms[name]["frame_equals_oracle"] is True, name
+        assert abs(forms[name]["ms_per_step"] / d["ms_per_step"] - 1.0) < 0.06, name
+    assert "REHEARSAL" not in forms["note"]

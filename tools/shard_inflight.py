@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Frame period of ONE rank's shard of the C3 frame (no collective), emulated on one GPU for N = 1, 2, 4, 8, against the
+"""Frame period of ONE rank's shard of the C3 frame (VRC_CONFIG=c4 / c5: of that configuration's; no collective), emulated on one GPU for N = 1, 2, 4, 8, against the
 number of frames in flight (renderers / streams used round-robin) and the work-unit policy: the library's automatic sample
 chunk (tuned for one launch at a time) with the resolve as a second kernel, or whole-spp units with the fused resolve
 (what bench.py uses when frames overlap).  Each figure is the best of three timed blocks."""
@@ -14,10 +14,11 @@ import torch
 import bench
 import cpuvoxelraycaster_amd as vrc
 
-cfg = bench.CONFIGS["c3"]
+CONFIG = os.environ.get("VRC_CONFIG", "c3")                     # c4: BASELINE config 4, the lens frame north_star shards over 8 GPUs
+cfg = bench.CONFIGS[CONFIG]
 depth, W, H, spp = cfg["depth"], cfg["width"], cfg["height"], cfg["spp"]
 svo = vrc.LSVO.fromFastNoiseTerrain(depth, textures=vrc.load_textures())
-cam = vrc.reference_camera(depth, pitch=-0.5)
+cam = vrc.reference_camera(depth, pitch=-0.5, aperture=cfg["aperture"], focal_length=(60.0 * (1 << depth) / 512.0 if cfg["aperture"] else 1.0))   # as bench.py
 L = vrc.capi.load()
 BLOCKS = int(os.environ.get("VRC_BLOCKS", "0"))
 LANE_SAMPLES = int(os.environ.get("VRC_LANE_SAMPLES", "0"))     # A/B of the lane <-> (pixel, sample) map (0 = the library's choice)
@@ -67,6 +68,7 @@ def period(N, F, whole):
 
 
 period(1, 2, True)      # warm-up
+print(f"config {CONFIG}: {cfg['label']}")
 print("N  frames in flight: 1 2 3 4 | automatic chunk + resolve kernel  ||  whole-spp units + fused resolve      (us per frame)")
 for N in (1, 2, 4, 8):
     a = [period(N, F, False) for F in (1, 2, 3, 4)]
