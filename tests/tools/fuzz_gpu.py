@@ -19,7 +19,11 @@ def main():
     ap.add_argument("--quad-bias", type=float, default=0.0,
                     help="probability that a frame case is steered to a launch the quadrant walks apply to (tree of 8+ levels, pinhole camera, "
                          "sample mode, units of a multiple of four samples, no reuse / checkerboard): the unbiased draw gets there in ~0.1 %% of the frames")
+    ap.add_argument("--depth10", type=float, default=0.0,
+                    help="probability that a steered terrain case runs on the 1024^3 tree (10 levels, BASELINE config 5's: the deepest stack "
+                         "the frame kernels are built for; generated once and kept) instead of 256^3 / 512^3 -- no draw at 0: old seeds replay")
     args = ap.parse_args()
+    deep = {}                                                    # the 1024^3 terrain and its 324 MB of nodes on the host, made once
     import collections
     kernels = collections.Counter()
     import cpuvoxelraycaster_amd as vrc
@@ -57,7 +61,14 @@ def main():
             quad_case = bool(args.quad_bias > 0 and rng.random() < args.quad_bias)     # (no draw at bias 0: old seeds replay)
             if rng.integers(0, 2):
                 depth = int(rng.choice([8, 9] if quad_case else [7, 8, 9]))
-                svo = vrc.LSVO.fromFastNoiseTerrain(depth, textures=(top, side))
+                if quad_case and args.depth10 > 0 and rng.random() < args.depth10:
+                    depth = 10
+                    if not deep:
+                        deep["svo"] = vrc.LSVO.fromFastNoiseTerrain(10, textures=(top, side))
+                        deep["nodes"] = deep["svo"].downloadNodes()
+                    svo = deep["svo"]
+                else:
+                    svo = vrc.LSVO.fromFastNoiseTerrain(depth, textures=(top, side))
             else:
                 # random blobs / slabs / noise volume: frames through arbitrary geometry, camera anywhere
                 depth = int(rng.integers(4, 8))
@@ -78,7 +89,7 @@ def main():
                     big[o[0]:o[0] + S0, o[1]:o[1] + S0, o[2]:o[2] + S0] = vol
                     vol, depth = big, 8
                 svo = vrc.LSVO.fromVolume(vol, depth, textures=(top, side))
-            nodes = svo.downloadNodes()
+            nodes = deep["nodes"] if svo is deep.get("svo") else svo.downloadNodes()
             W, H = int(rng.integers(1, 200)), int(rng.integers(1, 120))
             spp = int(rng.choice([4, 4, 8, 12, 16])) if quad_case else 0
             chunk = int(rng.choice([4, 8, spp])) if quad_case else int(rng.integers(0, 9))
@@ -154,7 +165,7 @@ def main():
                     mine = oacc[..., 3] > 0                                 # this shard's pixels
                     ok = ok and np.array_equal(rc.readImage()[mine], O.samples_to_image(oacc)[mine]) and not rc.readAccum().any()
             st = rc.stats()
-            kernels[rc.lastKernel()] += 1
+            kernels[rc.lastKernel() + (" @ depth 10" if depth == 10 else "")] += 1
             if reuse and cam.aperture == 0.0:
                 ok = ok and st.rays <= rr and st.sum_complexity <= ss
             else:
