@@ -49,6 +49,31 @@ def test_plain_bench_line_launches_its_ranks(built, world, gather):
         f.write(json.dumps(d) + "\n")
 
 
+def test_the_drivers_launch_line(built):
+    """the line the driver uses for N > 1, word for word: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W` (here N = 2 ranks sharing the box's one GPU,
+    hence VRC_DIST_BACKEND=gloo).  bench.py is then a rank, not a launcher: rc 0, rank 0's JSON line is the last line of
+    stdout, it says who launched it, validates itself and carries the three exchange forms."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["VRC_DIST_BACKEND"] = "gloo"
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+                          "--blocks", "1", "--blocks-min-seconds", "0"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    c = d["config"]
+    assert d["n_gpus"] == 2 and c["ranks_in_process_group"] == 2 and c["launched_by"] == "torch.distributed.run"
+    assert c["frame_equals_oracle"] is True and c["gathered_frame_equals_unsharded"] is True
+    forms = d["extra"]["exchange_forms"]
+    assert all(forms[f]["frame_equals_oracle"] is True for f in ("root", "all", "peer")) and "deadline" not in forms
+    log = os.path.join(ROOT, "gpurun_out", "r06")
+    os.makedirs(log, exist_ok=True)
+    with open(os.path.join(log, "torchrun_gloo2.json.log"), "w") as f:
+        f.write(json.dumps(d) + "\n")
+
+
 def test_the_extras_deadline_keeps_the_headline_line(built):
     """round 6: the block that measures the other exchange forms is untimed and must never cost the run its result.  With a
     deadline of 50 ms it cannot finish: rank 0 prints the headline line it already has -- parity bit and all, the reason under
